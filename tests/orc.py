@@ -1,0 +1,154 @@
+"""ctypes view of oracle/liboracle.so -- the CPU oracle (test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32),
+        ("focal", C.c_float), ("aspect", C.c_float),
+        ("cam_pos", C.c_float * 3), ("num_tris", C.c_uint32),
+        ("cam_quat", C.c_float * 4),
+        ("frame", C.c_uint32), ("mode", C.c_uint32),
+        ("spp", C.c_uint32), ("max_bounces", C.c_uint32), ("seed", C.c_uint32),
+        ("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32),
+        ("step_x", C.c_uint32), ("step_y", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "rays_closest", "rays_shadow", "nodes_examined", "tris_tested",
+        "node_fetches_ref", "stack_drops", "max_stack", "samples")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+MODE_PACKET, MODE_SINGLE, MODE_PATH = 0, 1, 2
+
+
+def focal_aspect(width, height):
+    """PathTracer.js:761-769: fov 70 deg, computed in double, stored as f32."""
+    import math
+    fov = (70.0 * math.pi) / 180
+    return np.float32(1.0 / math.tan(0.5 * fov)), np.float32(width / height)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        L = lib
+        L.orc_f32_to_f16_trunc.restype = C.c_uint32; L.orc_f32_to_f16_trunc.argtypes = [C.c_float]
+        L.orc_f32_to_f16_rtne.restype = C.c_uint32; L.orc_f32_to_f16_rtne.argtypes = [C.c_float]
+        L.orc_f16_to_f32.restype = C.c_float; L.orc_f16_to_f32.argtypes = [C.c_uint32]
+        L.orc_increment_f16.restype = C.c_float; L.orc_increment_f16.argtypes = [C.c_float, C.c_int]
+        L.orc_collapse_bvh4.restype = C.c_uint32
+        L.orc_render.restype = C.c_int
+        L.orc_trace_ray.restype = C.c_int
+        L.orc_rnd.restype = C.c_float; L.orc_rnd.argtypes = [C.c_uint32] * 5
+        L.orc_sincos_2pi.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_cosine_dir.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float)]
+
+    # ---- scene build -------------------------------------------------
+    def morton_sort(self, tris):
+        tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1)
+        n = tris.size // 9
+        m = np.zeros(n, np.uint32); t = np.zeros(n, np.uint32)
+        self.lib.orc_morton_sort(_p(tris, C.c_float), C.c_uint32(n), _p(m, C.c_uint32), _p(t, C.c_uint32))
+        return m, t
+
+    def build_lbvh2(self, tris, morton=None, tri_idx=None):
+        tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1)
+        n = tris.size // 9
+        if morton is None:
+            morton, tri_idx = self.morton_sort(tris)
+        out = np.zeros(1 + 6 * max(2 * n - 1, 0), np.uint32)
+        self.lib.orc_build_lbvh2(_p(tris, C.c_float), C.c_uint32(n), _p(morton, C.c_uint32), _p(tri_idx, C.c_uint32), _p(out, C.c_uint32))
+        return out
+
+    def collapse_bvh4(self, bvh2, num_tris):
+        bvh2 = np.ascontiguousarray(bvh2, dtype=np.uint32)
+        out = np.zeros(1 + 8 * max(2 * num_tris - 1, 0), np.uint32)
+        n4 = self.lib.orc_collapse_bvh4(_p(bvh2, C.c_uint32), C.c_uint32(num_tris), _p(out, C.c_uint32))
+        return out[: 1 + 8 * n4].copy(), int(n4)
+
+    def bvh4_wide(self, bvh2):
+        bvh2 = np.ascontiguousarray(bvh2, dtype=np.uint32)
+        out = np.zeros(1 + 8 * int(bvh2[0]), np.uint32)
+        self.lib.orc_bvh4_wide(_p(bvh2, C.c_uint32), _p(out, C.c_uint32))
+        return out
+
+    def build_bvh4(self, tris):
+        tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1)
+        n = tris.size // 9
+        bvh2 = self.build_lbvh2(tris)
+        bvh4, n4 = self.collapse_bvh4(bvh2, n)
+        return bvh2, bvh4
+
+    # ---- render ------------------------------------------------------
+    def make_params(self, width, height, num_tris, cam_pos=(0, 0, 2.5), cam_quat=(0, 0, 0, 1), mode=MODE_SINGLE,
+                    spp=1, max_bounces=0, seed=1, frame=0, rect=None, step=(1, 1)):
+        focal, aspect = focal_aspect(width, height)
+        p = Params()
+        p.width, p.height, p.focal, p.aspect = width, height, float(focal), float(aspect)
+        p.cam_pos[:] = [float(np.float32(v)) for v in cam_pos]
+        p.cam_quat[:] = [float(np.float32(v)) for v in cam_quat]
+        p.num_tris = num_tris
+        p.frame, p.mode, p.spp, p.max_bounces, p.seed = frame, mode, spp, max_bounces, seed
+        x0, y0, x1, y1 = rect if rect else (0, 0, width, height)
+        p.x0, p.y0, p.x1, p.y1 = x0, y0, x1, y1
+        p.step_x, p.step_y = step
+        return p
+
+    def render(self, params, tris, bvh4, want_tri_ids=False):
+        tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1)
+        bvh4 = np.ascontiguousarray(bvh4, dtype=np.uint32)
+        img = np.zeros((params.height, params.width, 4), np.float32)
+        ids = np.full((params.height, params.width), 0xFFFFFFFF, np.uint32) if want_tri_ids else None
+        st = Stats()
+        rc = self.lib.orc_render(C.byref(params), _p(tris, C.c_float), _p(bvh4, C.c_uint32), _p(img, C.c_float),
+                                 _p(ids, C.c_uint32) if want_tri_ids else None, C.byref(st))
+        assert rc == 0
+        return img, ids, st.as_dict()
+
+    def trace_ray(self, tris, bvh4, o, d, anyhit=False):
+        tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1)
+        bvh4 = np.ascontiguousarray(bvh4, dtype=np.uint32)
+        o = np.asarray(o, np.float32); d = np.asarray(d, np.float32)
+        t = C.c_float(); n = (C.c_float * 3)(); tri = C.c_uint32()
+        hit = self.lib.orc_trace_ray(_p(tris, C.c_float), _p(bvh4, C.c_uint32), C.c_uint32(tris.size // 9),
+                                     _p(o, C.c_float), _p(d, C.c_float), C.c_int(int(anyhit)), C.byref(t), n, C.byref(tri))
+        return bool(hit), t.value, np.array(list(n), np.float32), tri.value
+
+    def tonemap(self, rgba, quantize=True):
+        rgba = np.ascontiguousarray(rgba, np.float32)
+        h, w = rgba.shape[:2]
+        out = np.zeros((h, w, 4), np.uint8)
+        self.lib.orc_tonemap(_p(rgba, C.c_float), C.c_uint32(w), C.c_uint32(h), C.c_int(int(quantize)), _p(out, C.c_uint8))
+        return out
+
+
+def build():
+    """Compile the oracle (and oracle/_ref when the reference checkout is present)."""
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "all", "ref"])
+
+
+def load():
+    if not os.path.exists(LIB):
+        build()
+    return Oracle(C.CDLL(LIB))
