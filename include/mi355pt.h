@@ -1,0 +1,178 @@
+/* mi355pt.h -- C ABI of libmi355pt.so, the MI355X-native drop-in for the per-pixel-sample
+ * hot path of 31415Hacker/RayTracer-public (src/shaders/renderer.wgsl) and for the
+ * scene-build steps that feed it.
+ *
+ * This is the boundary a reference-side binding attaches to (N-API addon:
+ * raytracer-public_amd/napi/addon.c; ctypes: raytracer-public_amd/__init__.py; see
+ * INTEGRATION.md).  Plain pointers and sizes only.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every function returns a PtStatus (0 = OK); pt_last_error(ctx) gives the message of
+ *     the last failure on that context (pt_last_error(NULL): last context-less failure).
+ *     The reference signals errors by JS exceptions / rejected Promises
+ *     (src/libs/io.js:3, src/libs/Scene.js:27-30) -- the N-API layer turns a non-zero status
+ *     into exactly that.
+ *   - host arrays are copied during the call and never retained, like queue.writeBuffer
+ *     (src/libs/PathTracer.js:679,692-699,740,789).
+ *   - one context = one GPU = one caller thread at a time; work is issued in order on one HIP
+ *     stream (the WebGPU queue of the reference is in-order as well).
+ *   - buffer layouts are the reference's own:
+ *       triangles  f32[9*N]            v0xyz v1xyz v2xyz               (renderer.wgsl:82-89)
+ *       BVH2       u32[1 + 6*(2N-1)]   word0 = node count              (BVHBuilder.wgsl:5-7,83-132)
+ *       BVH (BVH4) u32[1 + 8*M]        word0 = node count              (renderer.wgsl:91-111)
+ *     radiance out: f32 RGBA, row py, column px, py = 0 <-> p.y = -1 (no flip; renderer.wgsl:387-411).
+ */
+#ifndef MI355PT_H
+#define MI355PT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PtContext PtContext;
+
+typedef enum PtStatus {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARG = 1,
+    PT_ERR_NO_DEVICE = 2,     /* no HIP device / HIP runtime failure at create */
+    PT_ERR_HIP = 3,           /* a HIP call failed (message in pt_last_error) */
+    PT_ERR_NO_SCENE = 4,      /* render / readback before triangles + BVH were set */
+    PT_ERR_BAD_BVH = 5,       /* malformed BVH buffer (size, child index, cycle) */
+    PT_ERR_IO = 6,
+    PT_ERR_OOM = 7
+} PtStatus;
+
+/* renderer modes */
+enum {
+    PT_MODE_REFERENCE_PACKET = 0, /* literal renderer.wgsl:355-413: one thread per 2x2 packet, shared stack + lane masks */
+    PT_MODE_REFERENCE        = 1, /* same image, one ray per lane (identical except on exact-t ties) */
+    PT_MODE_PATH             = 2  /* build-defined extension: spp, bounces, NEE, Russian roulette */
+};
+
+/* Mirrors RendererUBO (renderer.wgsl:14-19, packed at PathTracer.js:764-787) plus the
+ * build-defined extension fields. */
+typedef struct PtRenderParams {
+    uint32_t width, height;      /* resolution.xy  */
+    float    focal, aspect;      /* resolution.zw: 1/tan(35 deg), W/H (PathTracer.js:761-769) */
+    float    cam_pos[3];         /* camPosNumTris.xyz */
+    uint32_t num_tris;           /* u32(camPosNumTris.w) (renderer.wgsl:398); must be <= uploaded count */
+    float    cam_quat[4];        /* camQuat xyzw */
+    uint32_t frame;              /* frameCounter.x (unused by the reference shader; sample index base in PT_MODE_PATH) */
+    uint32_t mode;               /* PT_MODE_* */
+    uint32_t spp;                /* PT_MODE_PATH: samples per pixel this frame (>= 1) */
+    uint32_t max_bounces;        /* PT_MODE_PATH: indirect bounces after the primary hit */
+    uint32_t seed;               /* PT_MODE_PATH: RNG seed */
+    uint32_t accumulate;         /* PT_MODE_PATH: 0 = replace, 1 = add this frame to the running per-pixel sum */
+    uint32_t tile_rank;          /* pixel-tile sharding: this context renders 8x8 tiles with (tx+ty) % tile_count == tile_rank */
+    uint32_t tile_count;         /* 0 or 1 = whole frame, row-major output */
+    uint32_t flags;              /* PT_FLAG_* */
+} PtRenderParams;
+
+enum {
+    PT_FLAG_STATS = 1u           /* run the instrumented kernel variant and fill PtStats */
+};
+
+/* Traversal counters of the last PT_FLAG_STATS render (algorithmic-bytes bookkeeping,
+ * bytes = 32*nodes_examined + 36*tris_tested + 16*samples). */
+typedef struct PtStats {
+    uint64_t rays_closest, rays_shadow;
+    uint64_t nodes_examined;     /* node records box-tested, each once per examination */
+    uint64_t tris_tested;
+    uint64_t stack_drops;        /* pushes dropped at the 64-entry cap (renderer.wgsl:337) */
+    uint64_t max_stack;
+    uint64_t samples;
+} PtStats;
+
+/* ---- library / context ------------------------------------------------------------ */
+
+/* PathTracer.initialize() (PathTracer.js:97-173): picks the device, creates the stream and
+ * the fixed-size buffers.  device_ordinal < 0 selects the current HIP device. */
+int  pt_create(int device_ordinal, PtContext** out);
+void pt_destroy(PtContext* ctx);
+const char* pt_last_error(const PtContext* ctx);
+const char* pt_version(void);
+/* Issue all work of this context on a caller-owned hipStream_t (e.g. torch's current
+ * stream) instead of the context's own stream.  NULL restores the own stream. */
+int  pt_set_stream(PtContext* ctx, void* hip_stream);
+int  pt_synchronize(PtContext* ctx);
+
+/* ---- host-side scene build (no GPU touched; the reference runs these in JS) ------------ */
+
+/* computeBVH2Sizing / computeBVH4Sizing (PathTracer.js:227-238) */
+int pt_compute_bvh2_sizing(uint32_t num_tris, uint32_t* num_nodes2, uint64_t* bytes);
+int pt_compute_bvh4_sizing(uint32_t num_nodes4, uint64_t* bytes);
+/* buildMortonAndSort (PathTracer.js:427-481): outputs hold num_tris words each */
+int pt_morton_sort(const float* tris, uint32_t num_tris, uint32_t* morton_sorted, uint32_t* tri_index_sorted);
+/* collapseLBVH2ToBVH4 (PathTracer.js:506-667): out holds up to 1 + 8*(2N-1) words */
+int pt_collapse_lbvh2_to_bvh4(const uint32_t* bvh2, uint32_t num_tris, uint32_t* out, uint64_t out_words, uint32_t* num_nodes4);
+/* BVH2 -> BVH4_wide promotion (tests/test.cpp:106-196): out holds 1 + 8*bvh2[0] words */
+int pt_bvh2_to_bvh4_wide(const uint32_t* bvh2, uint64_t bvh2_words, uint32_t* out, uint64_t out_words);
+/* data/BVH2.bin, data/BVH4_wide.bin: raw little-endian u32 dumps (src/server/api.js:27-31,
+ * tests/test.cpp:16-33).  pt_file_read_u32 returns the word count through *words; call with
+ * dst = NULL to query the size. */
+int pt_file_write_u32(const char* path, const uint32_t* src, uint64_t words);
+int pt_file_read_u32(const char* path, uint32_t* dst, uint64_t dst_words, uint64_t* words);
+
+/* Deterministic procedural stand-in scenes (the reference's dragon.glb / Sponza are absent,
+ * SURVEY.md 0.3).  kind 0 = "dragon-class" closed bumpy knot, kind 1 = "sponza-class"
+ * interior.  Writes exactly num_tris triangles (9 f32 each), normalised to [-1,1]^3. */
+int pt_scene_procedural(uint32_t kind, uint32_t seed, uint32_t num_tris, float* tris_out);
+
+/* ---- device scene state ------------------------------------------------------------ */
+
+/* device.queue.writeBuffer(triangles) (PathTracer.js:679); N <= 932,067 in the reference
+ * (32 MiB buffer, :140-143) -- no such cap here. */
+int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris);
+/* buildBVH (PathTracer.js:671-749): Morton+sort, LBVH2 kernels (BVHBuilder.wgsl), readback,
+ * greedy collapse to BVH4, upload. */
+int pt_build_bvh(PtContext* ctx);
+/* LBVH2 kernels only, from caller-supplied sorted codes (the two dispatches at
+ * PathTracer.js:709-728); result stays on the device for pt_read_bvh2. */
+int pt_build_lbvh2(PtContext* ctx, const uint32_t* morton_sorted, const uint32_t* tri_index_sorted);
+/* readBVH2 (PathTracer.js:485-502): copies min(bytes, buffer size) bytes */
+int pt_read_bvh2(PtContext* ctx, uint32_t* dst, uint64_t bytes);
+/* writeBuffer(BVH) (PathTracer.js:739-740): install a BVH4 buffer in the reference layout
+ * (collapse output or BVH4_wide).  Validated: sizes, child indices, no node reachable twice. */
+int pt_set_bvh4(PtContext* ctx, const uint32_t* bvh4, uint64_t words);
+/* load a BVH2 buffer (data/BVH2.bin) and collapse it like buildBVH does after readback */
+int pt_set_bvh2(PtContext* ctx, const uint32_t* bvh2, uint64_t words);
+int pt_read_bvh4(PtContext* ctx, uint32_t* dst, uint64_t bytes);
+int pt_scene_info(PtContext* ctx, uint32_t* num_tris, uint32_t* num_nodes2, uint32_t* num_nodes4);
+
+/* ---- the hot path ----------------------------------------------------------------- */
+
+/* PathTracer.render() compute pass (PathTracer.js:756-802 + renderer.wgsl:355-413).
+ * Asynchronous on the context's stream; results are read with pt_read_radiance. */
+int pt_render(PtContext* ctx, const PtRenderParams* params);
+/* Device time of the last pt_render's kernel(s), by hipEvents on the stream it ran on.
+ * Synchronises the stream. */
+int pt_last_render_ms(PtContext* ctx, float* ms);
+int pt_get_stats(PtContext* ctx, PtStats* out);
+/* Full-frame f32 RGBA W*H*4 (tile_count <= 1).  Synchronises. */
+int pt_read_radiance(PtContext* ctx, float* dst, uint64_t dst_floats);
+/* rgba8unorm equivalent of the reference's outputTex (PathTracer.js:163-172) */
+int pt_read_rgba8(PtContext* ctx, uint8_t* dst, uint64_t dst_bytes);
+/* tonemapper.wgsl:24-41 applied to the last frame: Reinhard, gamma 1/2.2, vertical flip;
+ * from_rgba8 != 0 first quantises to rgba8unorm like the reference's texture. */
+int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t dst_bytes);
+
+/* ---- pixel-tile sharding across GPUs (one context per GPU / rank) ------------------ */
+
+/* Number of 8x8 tiles / pixels-slots this rank owns for a W x H frame split tile_count ways. */
+int pt_tile_layout(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count,
+                   uint32_t* num_tiles, uint64_t* compact_floats);
+/* Device pointer + size of this rank's compact radiance buffer (tile-major, 64 px per tile,
+ * f32 RGBA) after a render with tile_count > 1: the send buffer of the RCCL gather. */
+int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats);
+/* Rank 0: scatter `tile_count` gathered compact buffers (device memory, concatenated in rank
+ * order, each padded to `stride_floats`) into the context's full-frame radiance buffer. */
+int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride_floats,
+                    uint32_t width, uint32_t height, uint32_t tile_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355PT_H */

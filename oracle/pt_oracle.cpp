@@ -280,6 +280,10 @@ void build_lbvh2(const float* tris, uint32_t numTris, const uint32_t* morton,
 // Scene build: greedy collapse LBVH2 -> BVH4 (PathTracer.js:506-667)
 // ---------------------------------------------------------------------------
 
+// JS Math.min / Math.max (PathTracer.js:644-645): -0 orders below +0.
+inline double js_math_min(double a, double b) { if (a < b) return a; if (b < a) return b; return std::signbit(a) ? a : b; }
+inline double js_math_max(double a, double b) { if (a > b) return a; if (b > a) return b; return std::signbit(a) ? b : a; }
+
 struct Collapse {
     const uint32_t* b2; std::vector<uint32_t> out;
     bool is_leaf2(uint32_t i) const { return (b2[1 + i * NODE2_STRIDE + 5] & LEAF_FLAG) != 0; }
@@ -323,7 +327,7 @@ struct Collapse {
             uint32_t c0 = out[cb], c1 = out[cb + 1], c2 = out[cb + 2];
             double bmn[3] = {f16_to_f32(c0 & 0xFFFF), f16_to_f32(c0 >> 16), f16_to_f32(c1 & 0xFFFF)};
             double bmx[3] = {f16_to_f32(c1 >> 16), f16_to_f32(c2 & 0xFFFF), f16_to_f32(c2 >> 16)};
-            for (int k = 0; k < 3; k++) { mn[k] = std::fmin(mn[k], bmn[k]); mx[k] = std::fmax(mx[k], bmx[k]); }
+            for (int k = 0; k < 3; k++) { mn[k] = js_math_min(mn[k], bmn[k]); mx[k] = js_math_max(mx[k], bmx[k]); }
         }
         uint32_t base = 1 + idx4 * NODE4_STRIDE;  // encodeBounds (truncating), :560-566, 651
         out[base + 0] = f32_to_f16_trunc(float(mn[0])) | (f32_to_f16_trunc(float(mn[1])) << 16);

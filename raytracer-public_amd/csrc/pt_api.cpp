@@ -1,0 +1,506 @@
+// pt_api.cpp -- the C ABI of libmi355pt (include/mi355pt.h): context, device buffers, scene
+// upload / build, render dispatch, readback.  Mirrors the host side of the reference's
+// PathTracer class (src/libs/PathTracer.js); each entry point cites what it replaces in the
+// header.  No CPU fallback for device work: without a usable HIP device pt_create fails.
+#include "mi355pt.h"
+#include "pt_host.h"
+#include "pt_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_global_error;
+
+template <typename T>
+struct DevBuf {
+    T* ptr = nullptr; size_t cap = 0;   // capacity in elements
+    hipError_t ensure(size_t n) {
+        if (n <= cap && ptr) return hipSuccess;
+        if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+        if (n == 0) n = 1;
+        hipError_t e = hipMalloc((void**)&ptr, n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+};
+
+} // namespace
+
+struct PtContext {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    std::string err;
+
+    // scene (host mirrors kept for rebuilds / readback of small metadata only)
+    uint32_t num_tris = 0, num_nodes2 = 0, num_nodes4 = 0;
+    bool have_tris = false, have_bvh = false, have_bvh2 = false;
+    pt::WideBvh wide_meta;           // root info; nodes vector emptied after upload
+
+    DevBuf<float> d_tris9;           // reference layout
+    DevBuf<float4> d_trirec;         // 3 x float4 per triangle
+    DevBuf<uint32_t> d_bvh2, d_bvh4; // reference layouts
+    DevBuf<uint4> d_wide;            // 4 x uint4 per internal node
+    DevBuf<uint32_t> d_morton, d_triidx, d_parent, d_flags;
+
+    // frame
+    DevBuf<float4> d_out, d_accum, d_compact, d_compact_accum;
+    DevBuf<uint32_t> d_tiles, d_u32tmp;
+    DevBuf<unsigned long long> d_stats;
+    std::vector<uint32_t> tiles_host; uint32_t tiles_w = 0, tiles_h = 0, tiles_rank = 0, tiles_count = 0;
+    uint32_t out_w = 0, out_h = 0;   // dimensions of the last full-frame result in d_out
+    uint32_t accum_w = 0, accum_h = 0, accum_count = 0, accum_rank = 0;
+    uint64_t compact_floats = 0;
+    bool last_stats = false;
+};
+
+namespace {
+
+int fail(PtContext* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_global_error = msg;
+    return code;
+}
+int fail_hip(PtContext* ctx, hipError_t e, const char* what) {
+    return fail(ctx, PT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define PT_HIP(ctx, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail_hip((ctx), e__, #call); } while (0)
+
+int bind(PtContext* ctx) {
+    if (!ctx) return fail(nullptr, PT_ERR_INVALID_ARG, "null context");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    return PT_OK;
+}
+
+int upload_wide(PtContext* ctx, const uint32_t* bvh4, uint64_t words) {
+    pt::WideBvh w; std::string err;
+    if (!pt::build_wide_bvh(bvh4, words, w, err)) return fail(ctx, PT_ERR_BAD_BVH, err);
+    PT_HIP(ctx, ctx->d_bvh4.ensure(words));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh4.ptr, bvh4, words * 4, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, ctx->d_wide.ensure(w.nodes.size() * 4));
+    if (!w.nodes.empty())
+        PT_HIP(ctx, hipMemcpyAsync(ctx->d_wide.ptr, w.nodes.data(), w.nodes.size() * sizeof(pt::WideNode), hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die at return
+    ctx->num_nodes4 = w.num_nodes4;
+    w.nodes.clear(); w.nodes.shrink_to_fit();
+    ctx->wide_meta = w;
+    ctx->have_bvh = true;
+    return PT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* pt_version(void) { return "mi355pt 0.1 (gfx950)"; }
+
+const char* pt_last_error(const PtContext* ctx) { return ctx ? ctx->err.c_str() : g_global_error.c_str(); }
+
+int pt_create(int device_ordinal, PtContext** out) {
+    if (!out) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_create: null out pointer");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, PT_ERR_NO_DEVICE, std::string("pt_create: no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") + "); libmi355pt has no CPU path");
+    int dev = device_ordinal;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= count) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_create: device ordinal out of range");
+    e = hipSetDevice(dev);
+    if (e != hipSuccess) return fail_hip(nullptr, e, "hipSetDevice");
+    PtContext* ctx = new PtContext();
+    ctx->device = dev;
+    e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_start);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop);
+    if (e == hipSuccess) e = ctx->d_stats.ensure(8);
+    if (e != hipSuccess) { int rc = fail_hip(nullptr, e, "pt_create"); pt_destroy(ctx); return rc; }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_destroy(PtContext* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->d_tris9.release(); ctx->d_trirec.release(); ctx->d_bvh2.release(); ctx->d_bvh4.release(); ctx->d_wide.release();
+    ctx->d_morton.release(); ctx->d_triidx.release(); ctx->d_parent.release(); ctx->d_flags.release();
+    ctx->d_out.release(); ctx->d_accum.release(); ctx->d_compact.release(); ctx->d_compact_accum.release();
+    ctx->d_tiles.release(); ctx->d_u32tmp.release(); ctx->d_stats.release();
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int pt_set_stream(PtContext* ctx, void* hip_stream) {
+    if (int rc = bind(ctx)) return rc;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->timed = false;
+    return PT_OK;
+}
+
+int pt_synchronize(PtContext* ctx) {
+    if (int rc = bind(ctx)) return rc;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+// ---- host-side scene build ------------------------------------------------------------
+
+int pt_compute_bvh2_sizing(uint32_t num_tris, uint32_t* num_nodes2, uint64_t* bytes) {
+    const uint32_t nn = num_tris ? 2 * num_tris - 1 : 0;
+    if (num_nodes2) *num_nodes2 = nn;
+    if (bytes) *bytes = num_tris ? 4ull * (1ull + 6ull * nn) : 4ull;
+    return PT_OK;
+}
+int pt_compute_bvh4_sizing(uint32_t num_nodes4, uint64_t* bytes) {
+    if (bytes) *bytes = num_nodes4 ? 4ull * (1ull + 8ull * num_nodes4) : 4ull;
+    return PT_OK;
+}
+int pt_morton_sort(const float* tris, uint32_t num_tris, uint32_t* morton_sorted, uint32_t* tri_index_sorted) {
+    if (num_tris && (!tris || !morton_sorted || !tri_index_sorted)) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_morton_sort: null pointer");
+    pt::morton_codes_sorted(tris, num_tris, morton_sorted, tri_index_sorted);
+    return PT_OK;
+}
+int pt_collapse_lbvh2_to_bvh4(const uint32_t* bvh2, uint32_t num_tris, uint32_t* out, uint64_t out_words, uint32_t* num_nodes4) {
+    if (!out || (num_tris && !bvh2)) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_collapse_lbvh2_to_bvh4: null pointer");
+    std::vector<uint32_t> v; std::string err;
+    if (!pt::collapse_to_bvh4(bvh2, num_tris, v, err)) return fail(nullptr, PT_ERR_BAD_BVH, err);
+    if (v.size() > out_words) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_collapse_lbvh2_to_bvh4: output buffer too small");
+    std::memcpy(out, v.data(), v.size() * 4);
+    if (num_nodes4) *num_nodes4 = v[0];
+    return PT_OK;
+}
+int pt_bvh2_to_bvh4_wide(const uint32_t* bvh2, uint64_t bvh2_words, uint32_t* out, uint64_t out_words) {
+    if (!bvh2 || !out) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_bvh2_to_bvh4_wide: null pointer");
+    std::vector<uint32_t> v; std::string err;
+    if (!pt::promote_to_bvh4_wide(bvh2, bvh2_words, v, err)) return fail(nullptr, PT_ERR_BAD_BVH, err);
+    if (v.size() > out_words) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_bvh2_to_bvh4_wide: output buffer too small");
+    std::memcpy(out, v.data(), v.size() * 4);
+    return PT_OK;
+}
+int pt_file_write_u32(const char* path, const uint32_t* src, uint64_t words) {
+    if (!path || (!src && words)) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_file_write_u32: null pointer");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(nullptr, PT_ERR_IO, std::string("cannot open for writing: ") + path);
+    const size_t n = std::fwrite(src, 4, words, f);
+    const int rc = std::fclose(f);
+    if (n != words || rc != 0) return fail(nullptr, PT_ERR_IO, std::string("short write: ") + path);
+    return PT_OK;
+}
+int pt_file_read_u32(const char* path, uint32_t* dst, uint64_t dst_words, uint64_t* words) {
+    if (!path) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_file_read_u32: null path");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(nullptr, PT_ERR_IO, std::string("cannot open: ") + path);
+    std::fseek(f, 0, SEEK_END);
+    const long size = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (size <= 0 || (size & 3)) { std::fclose(f); return fail(nullptr, PT_ERR_IO, std::string("not a u32 dump (size): ") + path); }   // tests/test.cpp:20
+    const uint64_t n = uint64_t(size) / 4;
+    if (words) *words = n;
+    if (!dst) { std::fclose(f); return PT_OK; }
+    if (dst_words < n) { std::fclose(f); return fail(nullptr, PT_ERR_INVALID_ARG, "pt_file_read_u32: destination too small"); }
+    const size_t got = std::fread(dst, 4, n, f);
+    std::fclose(f);
+    if (got != n) return fail(nullptr, PT_ERR_IO, std::string("short read: ") + path);
+    return PT_OK;
+}
+int pt_scene_procedural(uint32_t kind, uint32_t seed, uint32_t num_tris, float* tris_out) {
+    std::string err;
+    if (!pt::procedural_scene(kind, seed, num_tris, tris_out, err)) return fail(nullptr, PT_ERR_INVALID_ARG, err);
+    return PT_OK;
+}
+
+// ---- device scene state ----------------------------------------------------------------
+
+int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris) {
+    if (int rc = bind(ctx)) return rc;
+    if (num_tris && !tris) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_triangles: null triangles");
+    if (num_tris >= 0x7fffffffu) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_triangles: too many triangles for the 31-bit leaf index");
+    PT_HIP(ctx, ctx->d_tris9.ensure(size_t(num_tris) * 9));
+    PT_HIP(ctx, ctx->d_trirec.ensure(size_t(num_tris) * 3));
+    std::vector<pt::TriRecord> rec(num_tris);
+    pt::build_tri_records(tris, num_tris, rec.data());
+    if (num_tris) {
+        PT_HIP(ctx, hipMemcpyAsync(ctx->d_tris9.ptr, tris, size_t(num_tris) * 36, hipMemcpyHostToDevice, ctx->stream));
+        PT_HIP(ctx, hipMemcpyAsync(ctx->d_trirec.ptr, rec.data(), size_t(num_tris) * sizeof(pt::TriRecord), hipMemcpyHostToDevice, ctx->stream));
+    }
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->num_tris = num_tris;
+    ctx->have_tris = true;
+    ctx->have_bvh = false; ctx->have_bvh2 = false;
+    ctx->accum_count = 0;
+    return PT_OK;
+}
+
+int pt_build_lbvh2(PtContext* ctx, const uint32_t* morton_sorted, const uint32_t* tri_index_sorted) {
+    if (int rc = bind(ctx)) return rc;
+    if (!ctx->have_tris) return fail(ctx, PT_ERR_NO_SCENE, "pt_build_lbvh2: no triangles uploaded");
+    const uint32_t n = ctx->num_tris;
+    uint32_t nn2 = 0; uint64_t bytes = 0;
+    pt_compute_bvh2_sizing(n, &nn2, &bytes);
+    PT_HIP(ctx, ctx->d_bvh2.ensure(bytes / 4));
+    ctx->num_nodes2 = nn2;
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh2.ptr, &nn2, 4, hipMemcpyHostToDevice, ctx->stream));   // BVH2[0] = numNodes2, PathTracer.js:699
+    if (n == 0) { PT_HIP(ctx, hipStreamSynchronize(ctx->stream)); ctx->have_bvh2 = true; return PT_OK; }
+    if (!morton_sorted || !tri_index_sorted) return fail(ctx, PT_ERR_INVALID_ARG, "pt_build_lbvh2: null sorted arrays");
+    for (uint32_t i = 0; i < n; ++i)
+        if (tri_index_sorted[i] >= n) return fail(ctx, PT_ERR_INVALID_ARG, "pt_build_lbvh2: triangle index out of range");
+    for (uint32_t i = 1; i < n; ++i)
+        if (morton_sorted[i] < morton_sorted[i - 1]) return fail(ctx, PT_ERR_INVALID_ARG, "pt_build_lbvh2: Morton codes are not sorted");
+    PT_HIP(ctx, ctx->d_morton.ensure(n)); PT_HIP(ctx, ctx->d_triidx.ensure(n));
+    PT_HIP(ctx, ctx->d_parent.ensure(nn2)); PT_HIP(ctx, ctx->d_flags.ensure(n > 1 ? n - 1 : 1));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_morton.ptr, morton_sorted, size_t(n) * 4, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_triidx.ptr, tri_index_sorted, size_t(n) * 4, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, ptk::launch_lbvh2(ctx->d_bvh2.ptr, ctx->d_tris9.ptr, ctx->d_morton.ptr, ctx->d_triidx.ptr, ctx->d_parent.ptr, ctx->d_flags.ptr, n, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // device.queue.onSubmittedWorkDone(), PathTracer.js:727
+    ctx->have_bvh2 = true;
+    return PT_OK;
+}
+
+int pt_read_bvh2(PtContext* ctx, uint32_t* dst, uint64_t bytes) {
+    if (int rc = bind(ctx)) return rc;
+    if (!ctx->have_bvh2) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_bvh2: no BVH2 on the device");
+    if (!dst) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_bvh2: null destination");
+    uint64_t have = 0; pt_compute_bvh2_sizing(ctx->num_tris, nullptr, &have);
+    const uint64_t n = bytes < have ? bytes : have;
+    PT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_bvh2.ptr, n, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_set_bvh4(PtContext* ctx, const uint32_t* bvh4, uint64_t words) {
+    if (int rc = bind(ctx)) return rc;
+    if (!bvh4 || words < 1) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_bvh4: empty buffer");
+    ctx->accum_count = 0;
+    return upload_wide(ctx, bvh4, words);
+}
+
+int pt_set_bvh2(PtContext* ctx, const uint32_t* bvh2, uint64_t words) {
+    if (int rc = bind(ctx)) return rc;
+    if (!ctx->have_tris) return fail(ctx, PT_ERR_NO_SCENE, "pt_set_bvh2: upload triangles first");
+    uint32_t nn2 = 0; uint64_t bytes = 0; pt_compute_bvh2_sizing(ctx->num_tris, &nn2, &bytes);
+    if (!bvh2 || words * 4 < bytes || bvh2[0] != nn2) return fail(ctx, PT_ERR_BAD_BVH, "pt_set_bvh2: buffer does not match 2N-1 nodes of the uploaded triangles");
+    PT_HIP(ctx, ctx->d_bvh2.ensure(bytes / 4));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh2.ptr, bvh2, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->num_nodes2 = nn2; ctx->have_bvh2 = true;
+    std::vector<uint32_t> b4; std::string err;
+    if (!pt::collapse_to_bvh4(bvh2, ctx->num_tris, b4, err)) return fail(ctx, PT_ERR_BAD_BVH, err);
+    ctx->accum_count = 0;
+    return upload_wide(ctx, b4.data(), b4.size());
+}
+
+int pt_build_bvh(PtContext* ctx) {
+    if (int rc = bind(ctx)) return rc;
+    if (!ctx->have_tris) return fail(ctx, PT_ERR_NO_SCENE, "pt_build_bvh: no triangles uploaded");
+    const uint32_t n = ctx->num_tris;
+    if (n == 0) {                                   // PathTracer.js:701-707: empty BVH4
+        const uint32_t zero = 0;
+        if (int rc = pt_build_lbvh2(ctx, nullptr, nullptr)) return rc;
+        return upload_wide(ctx, &zero, 1);
+    }
+    std::vector<float> tris(size_t(n) * 9);
+    PT_HIP(ctx, hipMemcpy(tris.data(), ctx->d_tris9.ptr, size_t(n) * 36, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> morton(n), tri_index(n);
+    pt::morton_codes_sorted(tris.data(), n, morton.data(), tri_index.data());
+    if (int rc = pt_build_lbvh2(ctx, morton.data(), tri_index.data())) return rc;
+    uint64_t bytes = 0; pt_compute_bvh2_sizing(n, nullptr, &bytes);
+    std::vector<uint32_t> bvh2(bytes / 4);
+    if (int rc = pt_read_bvh2(ctx, bvh2.data(), bytes)) return rc;       // PathTracer.js:731
+    std::vector<uint32_t> b4; std::string err;
+    if (!pt::collapse_to_bvh4(bvh2.data(), n, b4, err)) return fail(ctx, PT_ERR_BAD_BVH, err);   // :735
+    ctx->accum_count = 0;
+    return upload_wide(ctx, b4.data(), b4.size());                     // :739-740
+}
+
+int pt_read_bvh4(PtContext* ctx, uint32_t* dst, uint64_t bytes) {
+    if (int rc = bind(ctx)) return rc;
+    if (!ctx->have_bvh) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_bvh4: no BVH on the device");
+    if (!dst) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_bvh4: null destination");
+    const uint64_t have = 4ull * (1ull + 8ull * ctx->num_nodes4);
+    const uint64_t n = bytes < have ? bytes : have;
+    PT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_bvh4.ptr, n, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_scene_info(PtContext* ctx, uint32_t* num_tris, uint32_t* num_nodes2, uint32_t* num_nodes4) {
+    if (!ctx) return fail(nullptr, PT_ERR_INVALID_ARG, "null context");
+    if (num_tris) *num_tris = ctx->num_tris;
+    if (num_nodes2) *num_nodes2 = ctx->have_bvh2 ? ctx->num_nodes2 : 0;
+    if (num_nodes4) *num_nodes4 = ctx->have_bvh ? ctx->num_nodes4 : 0;
+    return PT_OK;
+}
+
+// ---- the hot path -----------------------------------------------------------------------
+
+int pt_tile_layout(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count, uint32_t* num_tiles, uint64_t* compact_floats) {
+    if (tile_count == 0) tile_count = 1;
+    if (tile_rank >= tile_count) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_tile_layout: rank >= count");
+    std::vector<uint32_t> t; pt::tile_list(width, height, tile_rank, tile_count, t);
+    if (num_tiles) *num_tiles = uint32_t(t.size());
+    if (compact_floats) *compact_floats = uint64_t(t.size()) * 64ull * 4ull;
+    return PT_OK;
+}
+
+int pt_render(PtContext* ctx, const PtRenderParams* p) {
+    if (int rc = bind(ctx)) return rc;
+    if (!p) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: null params");
+    if (!ctx->have_tris || !ctx->have_bvh) return fail(ctx, PT_ERR_NO_SCENE, "pt_render: scene not set (triangles + BVH)");   // PathTracer.js:757
+    if (p->width == 0 || p->height == 0 || p->width > 32768 || p->height > 32768) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: bad resolution");
+    if (p->num_tris > ctx->num_tris) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: num_tris exceeds the uploaded triangle count");
+    if (p->mode > PT_MODE_PATH) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: unknown mode");
+    if (p->mode == PT_MODE_PATH && p->spp == 0) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: spp must be >= 1");
+    const uint32_t count = p->tile_count ? p->tile_count : 1;
+    if (p->tile_rank >= count) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: tile_rank >= tile_count");
+    const bool sharded = count > 1;
+    if (sharded && p->mode == PT_MODE_REFERENCE_PACKET) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: the literal packet mode renders whole frames only");
+    const bool stats = (p->flags & PT_FLAG_STATS) != 0;
+    if (stats && p->mode == PT_MODE_REFERENCE_PACKET) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: no counters in the literal packet mode");
+
+    ptk::RenderArgs A; std::memset(&A, 0, sizeof(A));
+    A.nodes = ctx->d_wide.ptr; A.tris = ctx->d_trirec.ptr; A.bvh4_ref = ctx->d_bvh4.ptr; A.tris9 = ctx->d_tris9.ptr;
+    A.width = p->width; A.height = p->height; A.focal = p->focal; A.aspect = p->aspect;
+    std::memcpy(A.cam, p->cam_pos, 12); std::memcpy(A.quat, p->cam_quat, 16);
+    A.num_tris = p->num_tris; A.frame = p->frame;
+    A.root_ref = ctx->wide_meta.root_ref; std::memcpy(A.root_box, ctx->wide_meta.root_box, 12);
+    A.root_degenerate = ctx->wide_meta.root_degenerate ? 1u : 0u;
+    A.spp = p->spp; A.max_bounces = p->max_bounces; A.seed = p->seed; A.accumulate = 0; A.compact = sharded ? 1u : 0u;
+    A.tiles_x = (p->width + pt::kTile - 1) / pt::kTile;
+    const uint32_t tiles_y = (p->height + pt::kTile - 1) / pt::kTile;
+
+    const size_t npx = size_t(p->width) * p->height;
+    if (sharded) {
+        if (ctx->tiles_w != p->width || ctx->tiles_h != p->height || ctx->tiles_rank != p->tile_rank || ctx->tiles_count != count) {
+            pt::tile_list(p->width, p->height, p->tile_rank, count, ctx->tiles_host);
+            PT_HIP(ctx, ctx->d_tiles.ensure(ctx->tiles_host.size()));
+            if (!ctx->tiles_host.empty())
+                PT_HIP(ctx, hipMemcpyAsync(ctx->d_tiles.ptr, ctx->tiles_host.data(), ctx->tiles_host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->tiles_w = p->width; ctx->tiles_h = p->height; ctx->tiles_rank = p->tile_rank; ctx->tiles_count = count;
+        }
+        A.tiles = ctx->d_tiles.ptr; A.num_tiles = uint32_t(ctx->tiles_host.size());
+        PT_HIP(ctx, ctx->d_compact.ensure(size_t(A.num_tiles) * 64));
+        A.out = ctx->d_compact.ptr;
+        ctx->compact_floats = uint64_t(A.num_tiles) * 64ull * 4ull;
+    } else {
+        A.tiles = nullptr; A.num_tiles = A.tiles_x * tiles_y;
+        PT_HIP(ctx, ctx->d_out.ensure(npx));
+        A.out = ctx->d_out.ptr;
+        ctx->out_w = p->width; ctx->out_h = p->height;
+    }
+    if (p->mode == PT_MODE_PATH && p->accumulate) {
+        DevBuf<float4>& acc = sharded ? ctx->d_compact_accum : ctx->d_accum;
+        const size_t need = sharded ? size_t(A.num_tiles) * 64 : npx;
+        const bool cont = ctx->accum_count > 0 && ctx->accum_w == p->width && ctx->accum_h == p->height && ctx->accum_rank == (p->tile_rank | (count << 16)) && acc.cap >= need;
+        PT_HIP(ctx, acc.ensure(need));
+        A.accum = acc.ptr; A.accumulate = cont ? 1u : 0u;
+        ctx->accum_w = p->width; ctx->accum_h = p->height; ctx->accum_rank = p->tile_rank | (count << 16);
+        ctx->accum_count = cont ? ctx->accum_count + p->spp : p->spp;
+    } else {
+        ctx->accum_count = 0;
+    }
+    if (stats) {
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        A.stats = ctx->d_stats.ptr;
+    }
+    ctx->last_stats = stats;
+    PT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    const int kmode = p->mode == PT_MODE_REFERENCE_PACKET ? PT_KMODE_PACKET : (p->mode == PT_MODE_REFERENCE ? PT_KMODE_REFERENCE : PT_KMODE_PATH);
+    PT_HIP(ctx, ptk::launch_render(A, kmode, stats, ctx->stream));
+    PT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timed = true;
+    return PT_OK;
+}
+
+int pt_last_render_ms(PtContext* ctx, float* ms) {
+    if (int rc = bind(ctx)) return rc;
+    if (!ms) return fail(ctx, PT_ERR_INVALID_ARG, "pt_last_render_ms: null output");
+    if (!ctx->timed) return fail(ctx, PT_ERR_NO_SCENE, "pt_last_render_ms: nothing rendered yet");
+    PT_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
+    PT_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return PT_OK;
+}
+
+int pt_get_stats(PtContext* ctx, PtStats* out) {
+    if (int rc = bind(ctx)) return rc;
+    if (!out) return fail(ctx, PT_ERR_INVALID_ARG, "pt_get_stats: null output");
+    if (!ctx->last_stats) return fail(ctx, PT_ERR_NO_SCENE, "pt_get_stats: last render did not run with PT_FLAG_STATS");
+    unsigned long long h[8];
+    PT_HIP(ctx, hipMemcpyAsync(h, ctx->d_stats.ptr, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->rays_closest = h[0]; out->rays_shadow = h[1]; out->nodes_examined = h[2]; out->tris_tested = h[3];
+    out->stack_drops = h[4]; out->max_stack = h[5]; out->samples = h[6];
+    return PT_OK;
+}
+
+int pt_read_radiance(PtContext* ctx, float* dst, uint64_t dst_floats) {
+    if (int rc = bind(ctx)) return rc;
+    if (!dst) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_radiance: null destination");
+    const uint64_t need = uint64_t(ctx->out_w) * ctx->out_h * 4;
+    if (need == 0) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_radiance: no full-frame result (render with tile_count <= 1 or call pt_deinterleave)");
+    if (dst_floats < need) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_radiance: destination too small");
+    PT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_out.ptr, need * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_read_rgba8(PtContext* ctx, uint8_t* dst, uint64_t dst_bytes) {
+    if (int rc = bind(ctx)) return rc;
+    const uint64_t npx = uint64_t(ctx->out_w) * ctx->out_h;
+    if (npx == 0) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_rgba8: no full-frame result");
+    if (!dst || dst_bytes < npx * 4) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_rgba8: destination too small");
+    PT_HIP(ctx, ctx->d_u32tmp.ensure(npx));
+    PT_HIP(ctx, ptk::launch_rgba8(ctx->d_out.ptr, ctx->d_u32tmp.ptr, uint32_t(npx), ctx->stream));
+    PT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_u32tmp.ptr, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t dst_bytes) {
+    if (int rc = bind(ctx)) return rc;
+    const uint64_t npx = uint64_t(ctx->out_w) * ctx->out_h;
+    if (npx == 0) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_tonemapped: no full-frame result");
+    if (!dst || dst_bytes < npx * 4) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_tonemapped: destination too small");
+    PT_HIP(ctx, ctx->d_u32tmp.ensure(npx));
+    PT_HIP(ctx, ptk::launch_tonemap(ctx->d_out.ptr, ctx->d_u32tmp.ptr, ctx->out_w, ctx->out_h, from_rgba8, ctx->stream));
+    PT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_u32tmp.ptr, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats) {
+    if (int rc = bind(ctx)) return rc;
+    if (ctx->compact_floats == 0 || !ctx->d_compact.ptr) return fail(ctx, PT_ERR_NO_SCENE, "pt_compact_radiance: no tile-sharded render yet");
+    if (device_ptr) *device_ptr = ctx->d_compact.ptr;
+    if (floats) *floats = ctx->compact_floats;
+    return PT_OK;
+}
+
+int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride_floats, uint32_t width, uint32_t height, uint32_t tile_count) {
+    if (int rc = bind(ctx)) return rc;
+    if (!gathered_device || tile_count == 0 || (stride_floats & 3)) return fail(ctx, PT_ERR_INVALID_ARG, "pt_deinterleave: bad arguments");
+    for (uint32_t r = 0; r < tile_count; ++r) {
+        uint32_t nt = 0; pt_tile_layout(width, height, r, tile_count, &nt, nullptr);
+        if (uint64_t(nt) * 256ull > stride_floats) return fail(ctx, PT_ERR_INVALID_ARG, "pt_deinterleave: stride smaller than a rank's compact buffer");
+    }
+    const size_t npx = size_t(width) * height;
+    PT_HIP(ctx, ctx->d_out.ensure(npx));
+    PT_HIP(ctx, ptk::launch_deinterleave((const float4*)gathered_device, stride_floats / 4, ctx->d_out.ptr, width, height, tile_count, ctx->stream));
+    ctx->out_w = width; ctx->out_h = height;
+    return PT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,59 @@
+// pt_host.h -- host-side scene-build helpers of libmi355pt (no HIP calls in here).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace pt {
+
+constexpr uint32_t kNode2Stride = 6;            // BVHBuilder.wgsl:5
+constexpr uint32_t kNode4Stride = 8;            // renderer.wgsl:10
+constexpr uint32_t kLeafFlag    = 0x80000000u;  // renderer.wgsl:11
+constexpr uint32_t kInvalid     = 0xFFFFFFFFu;  // renderer.wgsl:12
+
+// ---- f16 codec -------------------------------------------------------------------
+float    half_to_float(uint32_t h);             // exact widening (PathTracer.js:16-40)
+uint32_t float_to_half_trunc(float v);          // PathTracer.js:42-51 semantics
+uint32_t float_to_half_rtne(float v);           // pinned rounding of WGSL pack2x16float
+
+// ---- scene build -----------------------------------------------------------------
+void morton_codes_sorted(const float* tris, uint32_t n, uint32_t* morton, uint32_t* tri_index);
+// returns false on a malformed BVH2 (message in err)
+bool collapse_to_bvh4(const uint32_t* bvh2, uint32_t num_tris, std::vector<uint32_t>& out, std::string& err);
+bool promote_to_bvh4_wide(const uint32_t* bvh2, uint64_t words, std::vector<uint32_t>& out, std::string& err);
+
+// ---- device layouts ----------------------------------------------
+// One 64-byte record per INTERNAL BVH4 node: the packed f16 boxes of its four children
+// (3 words each, reference packing) followed by four child references.
+struct WideNode {
+    uint32_t box[4][3];
+    uint32_t ref[4];   // kInvalid = empty slot; kLeafFlag|tri = leaf; else index of a WideNode
+};
+static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
+
+struct WideBvh {
+    std::vector<WideNode> nodes;
+    uint32_t root_ref = kInvalid;      // same encoding as WideNode::ref; kInvalid = empty BVH
+    uint32_t root_box[3] = {0, 0, 0};  // the root's own packed bounds
+    bool     root_degenerate = false;  // any(mn > mx) on the root (renderer.wgsl:244)
+    uint32_t num_nodes4 = 0;
+};
+// Validates the reference-layout BVH4 and builds the wide layout.  Rejects: short buffer,
+// child reachable twice / cycles.  Children that the reference skips for every ray
+// (INVALID, index >= numNodes, degenerate box: renderer.wgsl:288-291) become empty slots.
+bool build_wide_bvh(const uint32_t* bvh4, uint64_t words, WideBvh& out, std::string& err);
+
+// 48-byte triangle record: v0, e1 = v1-v0, e2 = v2-v0, n = normalize(cross(e1,e2)) -- the same
+// f32 operations renderer.wgsl:179-180,269 performs per visit, done once at upload.
+struct TriRecord { float v0[3], e1[3], e2[3], n[3]; };
+static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
+void build_tri_records(const float* tris, uint32_t n, TriRecord* out);
+
+// ---- procedural stand-in scenes ---------------------------------------------------
+bool procedural_scene(uint32_t kind, uint32_t seed, uint32_t num_tris, float* out, std::string& err);
+
+// ---- tiles ------------------------------------------------------------------------
+constexpr uint32_t kTile = 8;   // 8x8-pixel tiles, one wavefront each
+void tile_list(uint32_t width, uint32_t height, uint32_t rank, uint32_t count, std::vector<uint32_t>& tiles);
+
+} // namespace pt

@@ -1,0 +1,46 @@
+// pt_kernels.h -- kernel argument block and launchers shared by pt_kernels.hip and pt_api.cpp
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PT_KMODE_PACKET    0
+#define PT_KMODE_REFERENCE 1
+#define PT_KMODE_PATH      2
+
+namespace ptk {
+
+// Passed by value as the kernel argument (lives in SGPRs / the kernarg segment).
+struct RenderArgs {
+    // device scene, MI355X layouts
+    const uint4*  nodes;        // WideNode[]: 64 B per internal BVH4 node, read as 4 x dwordx4
+    const float4* tris;         // TriRecord[]: 48 B per triangle, read as 3 x dwordx4
+    // device scene, reference layouts (literal packet kernel, LBVH build, readback)
+    const uint32_t* bvh4_ref;   // u32[1 + 8*M]   renderer.wgsl:91-111
+    const float*    tris9;      // f32[9*N]       renderer.wgsl:82-89
+    // outputs
+    float4*   out;              // radiance: row-major W*H, or compact tile-major (64 px per owned tile)
+    float4*   accum;            // running per-pixel sums (xyz) + sample count (w); nullptr in reference modes
+    uint32_t* tri_ids;          // optional: closest-hit triangle of the primary ray (reference modes)
+    const uint32_t* tiles;      // owned tile ids, nullptr = every tile in row-major order
+    unsigned long long* stats;  // 7 counters (PtStats order)
+    uint32_t num_tiles, tiles_x;
+    // RendererUBO (renderer.wgsl:14-19)
+    uint32_t width, height; float focal, aspect;
+    float cam[3]; uint32_t num_tris;
+    float quat[4];
+    uint32_t frame;
+    // wide-BVH root
+    uint32_t root_ref; uint32_t root_box[3]; uint32_t root_degenerate;
+    // extension
+    uint32_t spp, max_bounces, seed, accumulate, compact;
+};
+
+hipError_t launch_render(const RenderArgs& args, int kmode, bool stats, hipStream_t stream);
+hipError_t launch_lbvh2(uint32_t* bvh2, const float* tris9, const uint32_t* morton, const uint32_t* tri_index,
+                        uint32_t* parent, uint32_t* flags, uint32_t num_tris, hipStream_t stream);
+hipError_t launch_deinterleave(const float4* gathered, uint64_t stride_px, float4* full, uint32_t width, uint32_t height,
+                               uint32_t count, hipStream_t stream);
+hipError_t launch_rgba8(const float4* src, uint32_t* dst, uint32_t n, hipStream_t stream);
+hipError_t launch_tonemap(const float4* src, uint32_t* dst, uint32_t width, uint32_t height, int from_rgba8, hipStream_t stream);
+
+} // namespace ptk

@@ -1,0 +1,618 @@
+// pt_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4):
+//   * render_rays_kernel      the per-pixel-sample hot path of renderer.wgsl (ray generation,
+//                             BVH4 traversal, Moller-Trumbore, shade) + the build-defined
+//                             path-tracing extension, one ray per lane
+//   * render_packet_kernel    the literal 2x2-packet form of renderer.wgsl:355-413
+//   * lbvh2_internal_kernel / lbvh2_leaves_kernel   BVHBuilder.wgsl:152-306
+//   * deinterleave_kernel, tonemap/quantise kernels
+//
+// Arithmetic contract: compiled with -ffp-contract=off; the only fused
+// operations are the explicit __builtin_fmaf sites; '/' and sqrtf are correctly rounded
+// (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt); f32 denormals are kept.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_kernels.h"
+
+namespace ptk {
+
+// ------------------------------------------------------------------------------------
+// small vector helpers (explicit operation order, never contracted)
+// ------------------------------------------------------------------------------------
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ F3 normalize3(F3 v) { const float inv = 1.0f / sqrtf(dot3(v, v)); return v * inv; }
+// WGSL min/max on non-NaN data (sign of zero never reaches a comparison result)
+__device__ __forceinline__ float wmin(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float wmax(float a, float b) { return (b > a) ? b : a; }
+
+__device__ __forceinline__ float half_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
+__device__ __forceinline__ float half_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+
+constexpr float kInfT = 1e30f;          // renderer.wgsl:64
+constexpr float kTriEps = 1e-7f;        // renderer.wgsl:178
+constexpr uint32_t kLeaf = 0x80000000u;
+constexpr uint32_t kInvalidRef = 0xFFFFFFFFu;
+constexpr int kStackMax = 64;           // renderer.wgsl:8
+
+struct Ray { F3 o, d, inv; };
+
+__device__ __forceinline__ F3 safe_inv(F3 d) {      // renderer.wgsl:74-80
+    return f3(fabsf(d.x) > 1e-8f ? 1.0f / d.x : kInfT,
+              fabsf(d.y) > 1e-8f ? 1.0f / d.y : kInfT,
+              fabsf(d.z) > 1e-8f ? 1.0f / d.z : kInfT);
+}
+
+__device__ __forceinline__ F3 rotate_quat(F3 v, const float* q) {   // renderer.wgsl:66-72
+    const F3 u = f3(q[0], q[1], q[2]); const float s = q[3];
+    const F3 uv = cross3(u, v), uuv = cross3(u, uv);
+    return f3(__builtin_fmaf(2.0f, __builtin_fmaf(s, uv.x, uuv.x), v.x),
+              __builtin_fmaf(2.0f, __builtin_fmaf(s, uv.y, uuv.y), v.y),
+              __builtin_fmaf(2.0f, __builtin_fmaf(s, uv.z, uuv.z), v.z));
+}
+
+__device__ __forceinline__ Ray primary_ray(const RenderArgs& A, float fx, float fy) {   // renderer.wgsl:387-395
+    const float uvx = fx / (float)A.width, uvy = fy / (float)A.height;
+    const float px = __builtin_fmaf(uvx, 2.0f, -1.0f), py = __builtin_fmaf(uvy, 2.0f, -1.0f);
+    Ray r;
+    r.d = rotate_quat(normalize3(f3(px * A.aspect, py, -A.focal)), A.quat);
+    r.o = f3(A.cam[0], A.cam[1], A.cam[2]);
+    r.inv = safe_inv(r.d);
+    return r;
+}
+
+// slab test of one packed f16 box (renderer.wgsl:147-159); returns hit, writes tmin
+__device__ __forceinline__ bool slab(const Ray& r, uint32_t w0, uint32_t w1, uint32_t w2, float best, float& tmin_out) {
+    const F3 mn = f3(half_lo(w0), half_hi(w0), half_lo(w1));
+    const F3 mx = f3(half_hi(w1), half_lo(w2), half_hi(w2));
+    const F3 t1 = (mn - r.o) * r.inv, t2 = (mx - r.o) * r.inv;
+    const float tmin = wmax(wmax(wmin(t1.x, t2.x), wmin(t1.y, t2.y)), wmin(t1.z, t2.z));
+    const float tmax = wmin(wmin(wmax(t1.x, t2.x), wmax(t1.y, t2.y)), wmax(t1.z, t2.z));
+    tmin_out = tmin;
+    return (tmax >= wmax(tmin, 0.0f)) && (tmin < best);
+}
+
+struct Counters { uint32_t nodes, tris, drops, maxstack; };
+
+// One-ray BVH4 traversal over the wide layout.  Visit order, tie-breaking and the 64-entry
+// stack cap are those of traverseBVH4Packet (renderer.wgsl:210-346) run with a single active
+// lane: hit children keep slot order, the nearest one (first minimum) trades places with the
+// first hit and is entered next; a stacked child is re-validated at pop by tmin < best.
+template <bool ANYHIT, bool STATS>
+__device__ __forceinline__ bool traverse(const RenderArgs& A, const Ray& r, float& best_t, uint32_t& best_tri,
+                                         uint2* __restrict__ stk, Counters& cnt) {
+    best_t = kInfT; best_tri = kInvalidRef;
+    if (A.root_ref == kInvalidRef || A.num_tris == 0u || A.root_degenerate) return false;
+    if (STATS) { cnt.nodes += 1; if (cnt.maxstack < 1u) cnt.maxstack = 1u; }
+    float troot;
+    if (!slab(r, A.root_box[0], A.root_box[1], A.root_box[2], best_t, troot)) return false;
+    uint32_t cur = A.root_ref;
+    int sp = 0;
+    for (;;) {
+        bool need_pop = false;
+        if (cur & kLeaf) {
+            const uint32_t ti = cur & 0x7fffffffu;
+            if (ti < A.num_tris) {
+                const float4* tp = A.tris + (size_t)ti * 3;
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                if (STATS) cnt.tris += 1;
+                const F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
+                const F3 p = cross3(r.d, e2);                    // renderer.wgsl:185-205
+                const float det = dot3(e1, p);
+                if (!(fabsf(det) < kTriEps)) {
+                    const float inv_det = 1.0f / det;
+                    const F3 s = r.o - v0;
+                    const float u = inv_det * dot3(s, p);
+                    if (!(u < 0.0f || u > 1.0f)) {
+                        const F3 q = cross3(s, e1);
+                        const float v = inv_det * dot3(r.d, q);
+                        if (!(v < 0.0f || (u + v) > 1.0f)) {
+                            const float t = inv_det * dot3(e2, q);
+                            if (t > kTriEps && t < best_t) {
+                                best_t = t; best_tri = ti;
+                                if (ANYHIT) return true;
+                            }
+                        }
+                    }
+                }
+            }
+            need_pop = true;
+        } else {
+            const uint4* np = A.nodes + (size_t)cur * 4;
+            const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            float t0, t1, t2, t3;
+            const bool h0 = (n3.x != kInvalidRef) && slab(r, n0.x, n0.y, n0.z, best_t, t0);
+            const bool h1 = (n3.y != kInvalidRef) && slab(r, n0.w, n1.x, n1.y, best_t, t1);
+            const bool h2 = (n3.z != kInvalidRef) && slab(r, n1.z, n1.w, n2.x, best_t, t2);
+            const bool h3 = (n3.w != kInvalidRef) && slab(r, n2.y, n2.z, n2.w, best_t, t3);
+            if (STATS) cnt.nodes += (n3.x != kInvalidRef) + (n3.y != kInvalidRef) + (n3.z != kInvalidRef) + (n3.w != kInvalidRef);
+            // nearest = first minimum in slot order (renderer.wgsl:315-318); first = first hit
+            int nslot = -1, fslot = -1; float tn = kInfT, tf = 0.0f; uint32_t rn = kInvalidRef, rf = kInvalidRef;
+            if (h0) { nslot = 0; tn = t0; rn = n3.x; fslot = 0; tf = t0; rf = n3.x; }
+            if (h1) { if (nslot < 0 || t1 < tn) { nslot = 1; tn = t1; rn = n3.y; } if (fslot < 0) { fslot = 1; tf = t1; rf = n3.y; } }
+            if (h2) { if (nslot < 0 || t2 < tn) { nslot = 2; tn = t2; rn = n3.z; } if (fslot < 0) { fslot = 2; tf = t2; rf = n3.z; } }
+            if (h3) { if (nslot < 0 || t3 < tn) { nslot = 3; tn = t3; rn = n3.w; } if (fslot < 0) { fslot = 3; tf = t3; rf = n3.w; } }
+            if (nslot < 0) {
+                need_pop = true;
+            } else {
+                // pushes far -> near (renderer.wgsl:336-342); the slot the nearest child left holds the first hit
+#define PT_PUSH(REF, TMIN) do { if (sp < kStackMax) { stk[sp] = make_uint2((REF), __float_as_uint(TMIN)); ++sp; } else if (STATS) { cnt.drops += 1; } } while (0)
+                if (h3) { if (nslot == 3) { if (fslot != 3) PT_PUSH(rf, tf); } else if (fslot != 3) PT_PUSH(n3.w, t3); }
+                if (h2) { if (nslot == 2) { if (fslot != 2) PT_PUSH(rf, tf); } else if (fslot != 2) PT_PUSH(n3.z, t2); }
+                if (h1) { if (nslot == 1) { if (fslot != 1) PT_PUSH(rf, tf); } else if (fslot != 1) PT_PUSH(n3.y, t1); }
+#undef PT_PUSH
+                if (STATS) { if ((uint32_t)(sp + 1) > cnt.maxstack) cnt.maxstack = (uint32_t)(sp + 1); }
+                if (sp < kStackMax) cur = rn;          // the push of the nearest child would have fitted
+                else { need_pop = true; if (STATS) cnt.drops += 1; }
+            }
+        }
+        if (need_pop) {
+            bool found = false;
+            while (sp > 0) {
+                --sp;
+                const uint2 e = stk[sp];
+                if (__uint_as_float(e.y) < best_t) { cur = e.x; found = true; break; }
+            }
+            if (!found) break;
+        }
+    }
+    return best_tri != kInvalidRef;
+}
+
+// ---- build-defined sampling; integer hash + fixed fmaf polynomials ----
+__device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__device__ __forceinline__ uint32_t sample_key(uint32_t seed, uint32_t pixel, uint32_t sidx) {
+    uint32_t h = mix32(seed + 0x9E3779B9u);
+    h = mix32(h ^ pixel);
+    return mix32(h ^ sidx);
+}
+__device__ __forceinline__ float rnd(uint32_t key, uint32_t bounce, uint32_t dim) {
+    const uint32_t h = mix32(key ^ (bounce * 8u + dim + 1u) * 0x9E3779B1u);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ void sincos_2pi(float u, float& c, float& s) {
+    const float q = u * 4.0f;
+    const float kf = floorf(q + 0.5f);
+    const float y = (q - kf) * 1.57079632679489662f;
+    const float y2 = y * y;
+    float sp = __builtin_fmaf(y2, 2.7557319e-6f, -1.9841270e-4f);
+    sp = __builtin_fmaf(y2, sp, 8.3333333e-3f);
+    sp = __builtin_fmaf(y2, sp, -1.6666667e-1f);
+    sp = __builtin_fmaf(y2, sp, 1.0f);
+    const float sy = y * sp;
+    float cp = __builtin_fmaf(y2, -2.7557319e-7f, 2.4801587e-5f);
+    cp = __builtin_fmaf(y2, cp, -1.3888889e-3f);
+    cp = __builtin_fmaf(y2, cp, 4.1666667e-2f);
+    cp = __builtin_fmaf(y2, cp, -0.5f);
+    const float cy = __builtin_fmaf(y2, cp, 1.0f);
+    const int k = (int)kf & 3;
+    c = (k == 0) ? cy : (k == 1) ? -sy : (k == 2) ? -cy : sy;
+    s = (k == 0) ? sy : (k == 1) ? cy : (k == 2) ? -sy : -cy;
+}
+__device__ __forceinline__ F3 cosine_dir(F3 n, float u1, float u2) {
+    float c, s; sincos_2pi(u2, c, s);
+    const float r = sqrtf(u1);
+    const float lx = r * c, ly = r * s, lz = sqrtf(1.0f - u1);
+    const float sign = copysignf(1.0f, n.z);
+    const float a = -1.0f / (sign + n.z);
+    const float b = n.x * n.y * a;
+    const F3 t = f3(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
+    const F3 bt = f3(b, sign + n.y * n.y * a, -n.y);
+    return (t * lx + bt * ly) + n * lz;
+}
+
+constexpr float kEpsOrigin = 1e-4f;
+constexpr float kBgPrimary = 0.01f;    // renderer.wgsl:410
+constexpr float kSkyAmbient = 0.15f;   // renderer.wgsl:352
+constexpr uint32_t kRRStart = 2;
+
+__device__ __forceinline__ F3 light_dir() { return normalize3(f3(1.0f, 1.5f, 1.0f)); }   // renderer.wgsl:349
+__device__ __forceinline__ F3 tri_normal(const RenderArgs& A, uint32_t ti) {
+    const float4 c = A.tris[(size_t)ti * 3 + 2];
+    return f3(c.y, c.z, c.w);
+}
+
+// One work item = one pixel.  A wavefront owns one 8x8 tile (lane = y*8+x inside the tile).
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(256) void render_rays_kernel(const RenderArgs A) {
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = item >> 6, lane = item & 63u;
+    if (slot >= A.num_tiles) return;
+    const uint32_t tile = A.tiles ? A.tiles[slot] : slot;
+    const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+    const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
+    if (px >= A.width || py >= A.height) return;
+    const size_t out_index = A.compact ? (size_t)item : ((size_t)py * A.width + px);
+
+    uint2 stk[kStackMax];
+    Counters cnt; cnt.nodes = cnt.tris = cnt.drops = cnt.maxstack = 0;
+    uint32_t n_closest = 0, n_shadow = 0;
+    const F3 base = f3(0.9f, 0.7f, 0.3f);
+    const F3 L = light_dir();
+
+    if (MODE == PT_KMODE_REFERENCE) {
+        const Ray r = primary_ray(A, (float)px + 0.5f, (float)py + 0.5f);
+        float t; uint32_t tri;
+        n_closest = 1;
+        const bool hit = traverse<false, STATS>(A, r, t, tri, stk, cnt);
+        F3 col = f3(0.01f, 0.01f, 0.01f);
+        if (hit) {                                           // shade(), renderer.wgsl:348-353
+            const float ndotl = wmax(dot3(tri_normal(A, tri), L), 0.0f);
+            col = base * (0.15f + ndotl);
+        }
+        A.out[out_index] = make_float4(col.x, col.y, col.z, 1.0f);
+        if (A.tri_ids) A.tri_ids[out_index] = tri;
+    } else {
+        const uint32_t pixel = py * A.width + px;
+        F3 sum = f3(0.0f, 0.0f, 0.0f);
+        for (uint32_t s = 0; s < A.spp; ++s) {
+            const uint32_t key = sample_key(A.seed, pixel, A.frame * A.spp + s);
+            Ray r = primary_ray(A, (float)px + rnd(key, 0, 0), (float)py + rnd(key, 0, 1));
+            F3 rad = f3(0.0f, 0.0f, 0.0f), T = f3(1.0f, 1.0f, 1.0f);
+            for (uint32_t bounce = 0;; ++bounce) {
+                float t; uint32_t tri;
+                ++n_closest;
+                const bool hit = traverse<false, STATS>(A, r, t, tri, stk, cnt);
+                if (!hit) { rad = rad + T * ((bounce == 0u) ? kBgPrimary : kSkyAmbient); break; }
+                const F3 n = tri_normal(A, tri);
+                const F3 hp = r.o + r.d * t;
+                const F3 nf = (dot3(n, r.d) < 0.0f) ? n : f3(-n.x, -n.y, -n.z);
+                const F3 so = hp + nf * kEpsOrigin;
+                const float ndl = dot3(nf, L);
+                if (ndl > 0.0f) {
+                    Ray sr; sr.o = so; sr.d = L; sr.inv = safe_inv(L);
+                    float st; uint32_t stri;
+                    ++n_shadow;
+                    if (!traverse<true, STATS>(A, sr, st, stri, stk, cnt)) rad = rad + (T * base) * ndl;
+                }
+                if (bounce >= A.max_bounces) break;
+                T = T * base;
+                if (bounce >= kRRStart) {
+                    const float p = wmax(wmax(T.x, T.y), T.z);
+                    if (rnd(key, bounce, 4) >= p) break;
+                    T = T * (1.0f / p);
+                }
+                r.d = cosine_dir(nf, rnd(key, bounce, 2), rnd(key, bounce, 3));
+                r.o = so; r.inv = safe_inv(r.d);
+            }
+            sum = sum + rad;
+        }
+        float count = (float)A.spp;
+        if (A.accum) {
+            float4 acc = A.accumulate ? A.accum[out_index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            sum = f3(acc.x + sum.x, acc.y + sum.y, acc.z + sum.z);
+            count = acc.w + count;
+            A.accum[out_index] = make_float4(sum.x, sum.y, sum.z, count);
+        }
+        const float inv = 1.0f / count;
+        A.out[out_index] = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, 1.0f);
+    }
+    if (STATS) {
+        atomicAdd(&A.stats[0], (unsigned long long)n_closest);
+        atomicAdd(&A.stats[1], (unsigned long long)n_shadow);
+        atomicAdd(&A.stats[2], (unsigned long long)cnt.nodes);
+        atomicAdd(&A.stats[3], (unsigned long long)cnt.tris);
+        atomicAdd(&A.stats[4], (unsigned long long)cnt.drops);
+        atomicMax(&A.stats[5], (unsigned long long)cnt.maxstack);
+        atomicAdd(&A.stats[6], (unsigned long long)(MODE == PT_KMODE_REFERENCE ? 1u : A.spp));
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Literal 2x2-packet kernel (renderer.wgsl:355-413): one thread per packet, reference-layout
+// BVH4 and 9-float triangles, shared 64-entry stack with a 4-bit lane mask per entry.
+// ------------------------------------------------------------------------------------
+struct PNode { F3 mn, mx; uint32_t c[4]; uint32_t tri; bool leaf; };
+__device__ __forceinline__ PNode load_ref_node(const uint32_t* __restrict__ bvh, uint32_t i) {   // renderer.wgsl:91-111
+    const uint32_t* p = bvh + 1 + (size_t)i * 8;
+    PNode n;
+    const uint32_t a = p[0], b = p[1], c = p[2];
+    n.mn = f3(half_lo(a), half_hi(a), half_lo(b));
+    n.mx = f3(half_hi(b), half_lo(c), half_hi(c));
+    n.c[0] = p[3]; n.c[1] = p[4]; n.c[2] = p[5]; n.c[3] = p[6];
+    n.leaf = (p[7] & kLeaf) != 0u; n.tri = p[7] & 0x7fffffffu;
+    return n;
+}
+__device__ __forceinline__ uint32_t packet_aabb(const Ray* rays, F3 mn, F3 mx, uint32_t in_mask, const float* best, float& min_t) {
+    min_t = kInfT;                                          // renderer.wgsl:121-169
+    if (mn.x > mx.x || mn.y > mx.y || mn.z > mx.z) return 0u;
+    uint32_t out = 0u; float m = kInfT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!(in_mask & (1u << i))) continue;
+        const F3 t1 = (mn - rays[i].o) * rays[i].inv, t2 = (mx - rays[i].o) * rays[i].inv;
+        const float tmin = wmax(wmax(wmin(t1.x, t2.x), wmin(t1.y, t2.y)), wmin(t1.z, t2.z));
+        const float tmax = wmin(wmin(wmax(t1.x, t2.x), wmax(t1.y, t2.y)), wmax(t1.z, t2.z));
+        if ((tmax >= wmax(tmin, 0.0f)) && (tmin < best[i])) { out |= 1u << i; m = wmin(m, tmin); }
+    }
+    min_t = out ? m : kInfT;
+    return out;
+}
+
+__global__ __launch_bounds__(256) void render_packet_kernel(const RenderArgs A) {
+    const uint32_t gx = blockIdx.x * 16u + (threadIdx.x & 15u), gy = blockIdx.y * 16u + (threadIdx.x >> 4);
+    const uint32_t bx = gx * 2u, by = gy * 2u;
+    if (bx >= A.width || by >= A.height) return;
+    Ray rays[4]; uint32_t lanes = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t px = bx + (i & 1), py = by + (i >> 1);
+        if (px < A.width && py < A.height) { lanes |= 1u << i; rays[i] = primary_ray(A, (float)px + 0.5f, (float)py + 0.5f); }
+        else { rays[i].o = f3(0, 0, 0); rays[i].d = f3(0, 0, -1.0f); rays[i].inv = f3(kInfT, kInfT, kInfT); }
+    }
+    float best[4] = {kInfT, kInfT, kInfT, kInfT};
+    uint32_t btri[4] = {kInvalidRef, kInvalidRef, kInvalidRef, kInvalidRef};
+    F3 bn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bn[i] = f3(0, 0, 0);
+    const uint32_t num_nodes = A.bvh4_ref[0];
+    if (num_nodes != 0u && A.num_tris != 0u && lanes != 0u) {
+        uint32_t stack[kStackMax]; uint8_t smask[kStackMax]; int sp = 0;
+        stack[0] = 0u; smask[0] = (uint8_t)lanes;
+        while (sp >= 0) {
+            const uint32_t ni = stack[sp]; const uint32_t lm = smask[sp]; --sp;
+            const PNode node = load_ref_node(A.bvh4_ref, ni);
+            if (node.mn.x > node.mx.x || node.mn.y > node.mx.y || node.mn.z > node.mx.z) continue;
+            float nmin; const uint32_t hm = packet_aabb(rays, node.mn, node.mx, lm, best, nmin);
+            if (!hm) continue;
+            if (node.leaf) {
+                if (node.tri < A.num_tris) {
+                    const float* tp = A.tris9 + (size_t)node.tri * 9;
+                    const F3 v0 = f3(tp[0], tp[1], tp[2]), v1 = f3(tp[3], tp[4], tp[5]), v2 = f3(tp[6], tp[7], tp[8]);
+                    const F3 e1 = v1 - v0, e2 = v2 - v0;
+                    const F3 tn = normalize3(cross3(e1, e2));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!(hm & (1u << i))) continue;
+                        const F3 p = cross3(rays[i].d, e2);
+                        const float det = dot3(e1, p);
+                        if (fabsf(det) < kTriEps) continue;
+                        const float inv_det = 1.0f / det;
+                        const F3 s = rays[i].o - v0;
+                        const float u = inv_det * dot3(s, p);
+                        if (u < 0.0f || u > 1.0f) continue;
+                        const F3 q = cross3(s, e1);
+                        const float v = inv_det * dot3(rays[i].d, q);
+                        if (v < 0.0f || (u + v) > 1.0f) continue;
+                        const float t = inv_det * dot3(e2, q);
+                        if (t > kTriEps && t < best[i]) { best[i] = t; bn[i] = tn; btri[i] = node.tri; }
+                    }
+                }
+                continue;
+            }
+            uint32_t cidx[4]; float cdist[4]; uint32_t cmask[4]; int cc = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t ci = node.c[c];
+                if (ci == kInvalidRef || ci >= num_nodes) continue;
+                const PNode ch = load_ref_node(A.bvh4_ref, ci);
+                if (ch.mn.x > ch.mx.x || ch.mn.y > ch.mx.y || ch.mn.z > ch.mx.z) continue;
+                float cm; const uint32_t m = packet_aabb(rays, ch.mn, ch.mx, hm, best, cm);
+                if (m) { cidx[cc] = ci; cdist[cc] = cm; cmask[cc] = m; ++cc; }
+            }
+            int bi = 0;
+            for (int i = 1; i < cc; ++i) bi = (cdist[i] < cdist[bi]) ? i : bi;
+            if (bi != 0) {
+                const uint32_t ti = cidx[0]; const float td = cdist[0]; const uint32_t tm = cmask[0];
+                cidx[0] = cidx[bi]; cdist[0] = cdist[bi]; cmask[0] = cmask[bi];
+                cidx[bi] = ti; cdist[bi] = td; cmask[bi] = tm;
+            }
+            for (int i = cc - 1; i >= 0; --i)
+                if (sp + 1 < kStackMax) { ++sp; stack[sp] = cidx[i]; smask[sp] = (uint8_t)cmask[i]; }
+        }
+    }
+    const F3 base = f3(0.9f, 0.7f, 0.3f);
+    const F3 L = light_dir();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!(lanes & (1u << i))) continue;
+        const uint32_t px = bx + (i & 1), py = by + (i >> 1);
+        F3 col = f3(0.01f, 0.01f, 0.01f);
+        if (btri[i] != kInvalidRef) col = base * (0.15f + wmax(dot3(bn[i], L), 0.0f));
+        const size_t o = (size_t)py * A.width + px;
+        A.out[o] = make_float4(col.x, col.y, col.z, 1.0f);
+        if (A.tri_ids) A.tri_ids[o] = btri[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// LBVH2 build (BVHBuilder.wgsl).  f32 -> f16 is round-to-nearest-even (v_cvt_f16_f32).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f16_bits_rtne(float v) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)v); }
+__device__ __forceinline__ uint32_t step_f16(float v, bool up) {        // BVHBuilder.wgsl:63-81, returns f16 bits
+    const uint32_t bits = f16_bits_rtne(v);
+    uint32_t ord = (bits & 0x8000u) ? ((~bits) & 0xFFFFu) : (bits ^ 0x8000u);
+    ord = up ? ord + 1u : ord - 1u;
+    return ((ord & 0x8000u) ? (ord ^ 0x8000u) : ((~ord) & 0xFFFFu)) & 0xFFFFu;
+}
+__device__ __forceinline__ void store_bounds2(uint32_t* bvh2, uint32_t node, F3 mn, F3 mx) {   // BVHBuilder.wgsl:83-102
+    uint32_t* p = bvh2 + 1 + (size_t)node * 6;
+    const uint32_t w0 = step_f16(mn.x, false) | (step_f16(mn.y, false) << 16);
+    const uint32_t w1 = step_f16(mn.z, false) | (step_f16(mx.x, true) << 16);
+    const uint32_t w2 = step_f16(mx.y, true) | (step_f16(mx.z, true) << 16);
+    __hip_atomic_store(p + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int lbvh_delta(const uint32_t* __restrict__ morton, int i, int j, int n) {   // BVHBuilder.wgsl:134-149
+    if (j < 0 || j >= n) return -1;
+    const uint32_t x = morton[i] ^ morton[j];
+    if (x == 0u) return 32 + __clz((int)((uint32_t)i ^ (uint32_t)j));
+    return __clz((int)x);
+}
+
+__global__ __launch_bounds__(256) void lbvh2_internal_kernel(uint32_t* __restrict__ bvh2, const uint32_t* __restrict__ morton,
+                                                              uint32_t* __restrict__ parent, uint32_t* __restrict__ flags, uint32_t num_tris) {
+    const uint32_t iu = blockIdx.x * blockDim.x + threadIdx.x;     // BVHBuilder.wgsl:152-240
+    if (num_tris <= 1u || iu >= num_tris - 1u) return;
+    const int n = (int)num_tris, i = (int)iu;
+    flags[iu] = 0u;
+    const int d = (lbvh_delta(morton, i, i + 1, n) - lbvh_delta(morton, i, i - 1, n)) > 0 ? 1 : -1;
+    const int dmin = lbvh_delta(morton, i, i - d, n);
+    int lmax = 2;
+    while (lbvh_delta(morton, i, i + lmax * d, n) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t > 0; t >>= 1)
+        if (lbvh_delta(morton, i, i + (l + t) * d, n) > dmin) l += t;
+    const int j = i + l * d;
+    const int first = min(i, j), last = max(i, j);
+    const int dnode = lbvh_delta(morton, first, last, n);
+    int split = first, step = last - first;
+    while (step > 1) {
+        step = (step + 1) >> 1;
+        const int ns = split + step;
+        if (ns < last && lbvh_delta(morton, first, ns, n) > dnode) split = ns;
+    }
+    const uint32_t leaf_base = num_tris - 1u;
+    const uint32_t lc = (split == first) ? leaf_base + (uint32_t)split : (uint32_t)split;
+    const uint32_t rc = (split + 1 == last) ? leaf_base + (uint32_t)(split + 1) : (uint32_t)(split + 1);
+    uint32_t* p = bvh2 + 1 + (size_t)iu * 6;
+    p[3] = lc; p[4] = rc; p[5] = 0u;
+    parent[lc] = iu; parent[rc] = iu;
+    if (iu == 0u) parent[0] = kInvalidRef;
+}
+
+__global__ __launch_bounds__(256) void lbvh2_leaves_kernel(uint32_t* bvh2, const float* __restrict__ tris, const uint32_t* __restrict__ tri_index,
+                                                            const uint32_t* __restrict__ parent, uint32_t* flags, uint32_t num_tris) {
+    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;   // BVHBuilder.wgsl:278-306
+    if (leaf >= num_tris) return;
+    const uint32_t internal = num_tris - 1u;
+    const uint32_t node = internal + leaf;
+    const uint32_t ti = tri_index[leaf];
+    const float* tp = tris + (size_t)ti * 9;
+    const F3 v0 = f3(tp[0], tp[1], tp[2]), v1 = f3(tp[3], tp[4], tp[5]), v2 = f3(tp[6], tp[7], tp[8]);
+    const F3 mn = f3(wmin(v0.x, wmin(v1.x, v2.x)), wmin(v0.y, wmin(v1.y, v2.y)), wmin(v0.z, wmin(v1.z, v2.z)));
+    const F3 mx = f3(wmax(v0.x, wmax(v1.x, v2.x)), wmax(v0.y, wmax(v1.y, v2.y)), wmax(v0.z, wmax(v1.z, v2.z)));
+    store_bounds2(bvh2, node, mn, mx);
+    uint32_t* p = bvh2 + 1 + (size_t)node * 6;
+    p[3] = 0u; p[4] = 0u; p[5] = kLeaf | (ti & 0x7fffffffu);
+    if (internal == 0u) return;
+    // bottom-up refit (BVHBuilder.wgsl:242-275).  The reference has no fence between a child's
+    // bounds store and the flag increment; here the stores are agent-scope, a release fence
+    // precedes the atomic and an acquire fence follows it (MI355X L2s are per XCD).
+    uint32_t cur = node;
+    for (;;) {
+        const uint32_t par = parent[cur];
+        if (par == kInvalidRef || par >= internal) break;
+        __threadfence();
+        const uint32_t old = atomicAdd(&flags[par], 1u);
+        if (old == 0u) break;
+        __threadfence();
+        const uint32_t* pp = bvh2 + 1 + (size_t)par * 6;
+        const uint32_t l = pp[3], r = pp[4];
+        const uint32_t* lp = bvh2 + 1 + (size_t)l * 6; const uint32_t* rp = bvh2 + 1 + (size_t)r * 6;
+        const uint32_t l0 = __hip_atomic_load(lp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), l1 = __hip_atomic_load(lp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), l2 = __hip_atomic_load(lp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t r0 = __hip_atomic_load(rp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), r1 = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), r2 = __hip_atomic_load(rp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const F3 umn = f3(wmin(half_lo(l0), half_lo(r0)), wmin(half_hi(l0), half_hi(r0)), wmin(half_lo(l1), half_lo(r1)));
+        const F3 umx = f3(wmax(half_hi(l1), half_hi(r1)), wmax(half_lo(l2), half_lo(r2)), wmax(half_hi(l2), half_hi(r2)));
+        store_bounds2(bvh2, par, umn, umx);
+        cur = par;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// post passes
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void deinterleave_kernel(const float4* __restrict__ gathered, uint64_t stride_px, float4* __restrict__ full,
+                                                           uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t tiles_y, uint32_t count) {
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tile = item >> 6, lane = item & 63u;
+    if (tile >= tiles_x * tiles_y) return;
+    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
+    if (px >= width || py >= height) return;
+    const uint32_t rank = (tx + ty) % count;
+    // slot of (tx,ty) in its rank's row-major list: tiles of that rank in earlier rows + earlier in this row
+    uint32_t slot = 0;
+    // rows above: row r holds tiles with tx = (rank - r) mod count, stepping by count
+    // closed form per row: number of tx in [0,tiles_x) with (tx + r) % count == rank
+    for (uint32_t r = 0; r < ty; ++r) {
+        const uint32_t first = (rank + count - (r % count)) % count;
+        slot += (first < tiles_x) ? (tiles_x - first + count - 1) / count : 0u;
+    }
+    const uint32_t first = (rank + count - (ty % count)) % count;
+    slot += (tx - first) / count;
+    full[(size_t)py * width + px] = gathered[(size_t)rank * stride_px + (size_t)slot * 64 + lane];
+}
+
+__global__ __launch_bounds__(256) void rgba8_kernel(const float4* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = src[i];
+    auto q = [](float v) { v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); return (uint32_t)floorf(v * 255.0f + 0.5f); };
+    dst[i] = q(c.x) | (q(c.y) << 8) | (q(c.z) << 16) | (q(c.w) << 24);
+}
+
+// tonemapper.wgsl:24-41 (Reinhard, gamma 1/2.2) with the vertical flip of the full-screen pass
+__global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__ src, uint32_t* __restrict__ dst, uint32_t width, uint32_t height, int from_rgba8) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    const uint32_t x = i % width, y = i / width;
+    const float4 c = src[(size_t)(height - 1u - y) * width + x];
+    auto tm = [from_rgba8](float v) {
+        if (from_rgba8) { v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); v = floorf(v * 255.0f + 0.5f) / 255.0f; }
+        const float m = v / (v + 1.0f);
+        float g = powf(m, 1.0f / 2.2f);
+        g = g < 0.0f ? 0.0f : (g > 1.0f ? 1.0f : g);
+        return (uint32_t)floorf(g * 255.0f + 0.5f);
+    };
+    dst[i] = tm(c.x) | (tm(c.y) << 8) | (tm(c.z) << 16) | (255u << 24);
+}
+
+// ------------------------------------------------------------------------------------
+// launchers (called from pt_api.cpp)
+// ------------------------------------------------------------------------------------
+hipError_t launch_render(const RenderArgs& A, int kmode, bool stats, hipStream_t stream) {
+    if (kmode == PT_KMODE_PACKET) {
+        const dim3 grid((A.width + 31) / 32, (A.height + 31) / 32);   // 16x16 threads, 2x2 pixels each
+        hipLaunchKernelGGL(render_packet_kernel, grid, dim3(256), 0, stream, A);
+        return hipGetLastError();
+    }
+    const uint32_t items = A.num_tiles * 64u;
+    const dim3 grid((items + 255u) / 256u), block(256);
+    if (grid.x == 0) return hipSuccess;
+    if (kmode == PT_KMODE_REFERENCE) {
+        if (stats) hipLaunchKernelGGL((render_rays_kernel<PT_KMODE_REFERENCE, true>), grid, block, 0, stream, A);
+        else       hipLaunchKernelGGL((render_rays_kernel<PT_KMODE_REFERENCE, false>), grid, block, 0, stream, A);
+    } else {
+        if (stats) hipLaunchKernelGGL((render_rays_kernel<PT_KMODE_PATH, true>), grid, block, 0, stream, A);
+        else       hipLaunchKernelGGL((render_rays_kernel<PT_KMODE_PATH, false>), grid, block, 0, stream, A);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_lbvh2(uint32_t* bvh2, const float* tris9, const uint32_t* morton, const uint32_t* tri_index,
+                        uint32_t* parent, uint32_t* flags, uint32_t num_tris, hipStream_t stream) {
+    if (num_tris == 0) return hipSuccess;
+    if (num_tris > 1) {
+        hipLaunchKernelGGL(lbvh2_internal_kernel, dim3((num_tris - 1 + 255) / 256), dim3(256), 0, stream, bvh2, morton, parent, flags, num_tris);
+        hipError_t e = hipGetLastError(); if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(lbvh2_leaves_kernel, dim3((num_tris + 255) / 256), dim3(256), 0, stream, bvh2, tris9, tri_index, parent, flags, num_tris);
+    return hipGetLastError();
+}
+
+hipError_t launch_deinterleave(const float4* gathered, uint64_t stride_px, float4* full, uint32_t width, uint32_t height, uint32_t count, hipStream_t stream) {
+    const uint32_t tx = (width + 7) / 8, ty = (height + 7) / 8;
+    const uint32_t items = tx * ty * 64u;
+    hipLaunchKernelGGL(deinterleave_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, gathered, stride_px, full, width, height, tx, ty, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_rgba8(const float4* src, uint32_t* dst, uint32_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(rgba8_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, dst, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_tonemap(const float4* src, uint32_t* dst, uint32_t width, uint32_t height, int from_rgba8, hipStream_t stream) {
+    hipLaunchKernelGGL(tonemap_kernel, dim3((width * height + 255) / 256), dim3(256), 0, stream, src, dst, width, height, from_rgba8);
+    return hipGetLastError();
+}
+
+} // namespace ptk

@@ -24,3 +24,17 @@ def golden_js():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "pathtracer_js_golden.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def rt():
+    """The product package (ctypes binding of libmi355pt.so)."""
+    import importlib
+    return importlib.import_module("raytracer-public_amd")
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(rt):
+    ctx = rt.Context(0)
+    yield ctx
+    ctx.close()

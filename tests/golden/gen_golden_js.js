@@ -55,10 +55,11 @@ function randomBVH2(n) {
     const r = lcg() % 100;
     let e, m = lcg() & 0x3ff;
     if (r < 8) e = 0; else e = 8 + (lcg() % 8);      // subnormal or ~[2^-7, 2^0]
+    if (r < 3) m = 0;                                 // exact +0 / -0 (Math.min(+0,-0) = -0 matters)
     const s = (lcg() & 1) ? 0x8000 : 0;
     return h(s | (e << 10) | m);
   }
-  const f16val = (b) => { const s = (b & 0x8000) ? -1 : 1, e = (b >> 10) & 31, m = b & 0x3ff; return e === 0 ? s * m * Math.pow(2, -24) : s * (1 + m / 1024) * Math.pow(2, e - 15); };
+  const f16val = (b) => { if ((b & 0x7fff) === 0) return (b & 0x8000) ? -1e-30 : 1e-30; const s = (b & 0x8000) ? -1 : 1, e = (b >> 10) & 31, m = b & 0x3ff; return e === 0 ? s * m * Math.pow(2, -24) : s * (1 + m / 1024) * Math.pow(2, e - 15); };
   const bounds = new Array(numNodes);
   let nextInternal = 0;
   function build(first, last) { // leaves [first,last]

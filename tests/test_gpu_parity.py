@@ -1,0 +1,174 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Integer work (BVH buffers) and f32 radiance are both compared BIT-EXACTLY: the
+arithmetic contract of DESIGN.md section 3 makes the two paths the same sequence of IEEE
+operations; the north-star tolerance (1e-4 relative L2) is asserted as well."""
+import numpy as np
+import pytest
+
+import orc as orc_mod
+from scenes import TETRA, random_soup, quat_yaw_pitch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (2, 1), (3, 2), (4, 3), (100, 4), (5000, 5), (120000, 6)])
+def test_lbvh2_kernels_bit_exact(rt, orc, gpu_ctx, n, seed):
+    tris = TETRA if n == 4 else random_soup(n, seed)
+    m, t = rt.morton_sort(tris)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_lbvh2(m, t)
+    got = gpu_ctx.read_bvh2()
+    want = orc.build_lbvh2(tris, m, t)
+    assert np.array_equal(got, want)
+
+
+def test_lbvh2_tetra_known_answer(rt, gpu_ctx):
+    # leaf bounds of the default tetrahedron = [-1,1]^3 widened by one f16 ULP
+    m, t = rt.morton_sort(TETRA)
+    gpu_ctx.set_triangles(TETRA)
+    gpu_ctx.build_lbvh2(m, t)
+    b = gpu_ctx.read_bvh2()
+    assert b[0] == 7
+    for node in range(3, 7):
+        assert list(b[1 + 6 * node: 4 + 6 * node]) == [0xBC01BC01, 0x3C01BC01, 0x3C013C01]
+    assert [int(b[1 + 6 * node + 5]) for node in range(3, 7)] == [0x80000003, 0x80000000, 0x80000002, 0x80000001]
+
+
+@pytest.mark.parametrize("n,seed", [(4, 0), (777, 1), (30000, 2)])
+def test_build_bvh_end_to_end(rt, orc, gpu_ctx, n, seed):
+    tris = TETRA if n == 4 else random_soup(n, seed)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    bvh2, bvh4 = orc.build_bvh4(tris)
+    assert np.array_equal(gpu_ctx.read_bvh2(), bvh2)
+    assert np.array_equal(gpu_ctx.read_bvh4(), bvh4)
+
+
+CAMS = [((0, 0, 2.5), (0, 0, 0, 1)), ((0.4, 0.3, 1.7), quat_yaw_pitch(0.2, -0.15)), ((0, 0, 0), quat_yaw_pitch(2.0, 0.4))]
+
+
+def _scene(rt, orc, gpu_ctx, kind):
+    if kind == "tetra":
+        tris = TETRA
+    elif kind == "soup":
+        tris = random_soup(3000, 11)
+    else:
+        tris = rt.procedural_scene(0, 20000)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    return tris, gpu_ctx.read_bvh4()
+
+
+@pytest.mark.parametrize("kind", ["tetra", "soup", "dragon"])
+def test_reference_mode_single_ray_bit_exact(rt, orc, gpu_ctx, kind):
+    tris, bvh4 = _scene(rt, orc, gpu_ctx, kind)
+    w, h = 200, 120
+    for cam, quat in CAMS:
+        p = gpu_ctx.make_params(w, h, cam, quat, mode=rt.PT_MODE_REFERENCE, stats=True)
+        gpu_ctx.render(p)
+        img = gpu_ctx.read_radiance()
+        st = gpu_ctx.stats()
+        op = orc.make_params(w, h, tris.size // 9, cam, quat, mode=orc_mod.MODE_SINGLE)
+        ref, _, ost = orc.render(op, tris, bvh4)
+        assert rel_l2(img, ref) <= 1e-4
+        assert same_bits(img, ref)
+        for k in ("rays_closest", "nodes_examined", "tris_tested", "stack_drops", "max_stack", "samples"):
+            assert st[k] == ost[k], k
+
+
+@pytest.mark.parametrize("kind", ["tetra", "soup", "dragon"])
+def test_literal_packet_mode_bit_exact(rt, orc, gpu_ctx, kind):
+    tris, bvh4 = _scene(rt, orc, gpu_ctx, kind)
+    for (w, h) in [(200, 120), (33, 17)]:      # odd sizes: partially filled packets
+        cam, quat = CAMS[1]
+        gpu_ctx.render(gpu_ctx.make_params(w, h, cam, quat, mode=rt.PT_MODE_REFERENCE_PACKET))
+        img = gpu_ctx.read_radiance()
+        ref, _, _ = orc.render(orc.make_params(w, h, tris.size // 9, cam, quat, mode=orc_mod.MODE_PACKET), tris, bvh4)
+        assert same_bits(img, ref)
+
+
+@pytest.mark.parametrize("kind,spp,bounces", [("tetra", 2, 3), ("soup", 3, 4), ("dragon", 4, 8)])
+def test_path_mode_bit_exact(rt, orc, gpu_ctx, kind, spp, bounces):
+    tris, bvh4 = _scene(rt, orc, gpu_ctx, kind)
+    w, h = 160, 96
+    cam, quat = CAMS[0] if kind != "soup" else CAMS[2]
+    p = gpu_ctx.make_params(w, h, cam, quat, mode=rt.PT_MODE_PATH, spp=spp, max_bounces=bounces, seed=7, frame=3, stats=True)
+    gpu_ctx.render(p)
+    img = gpu_ctx.read_radiance()
+    st = gpu_ctx.stats()
+    op = orc.make_params(w, h, tris.size // 9, cam, quat, mode=orc_mod.MODE_PATH, spp=spp, max_bounces=bounces, seed=7, frame=3)
+    ref, _, ost = orc.render(op, tris, bvh4)
+    assert rel_l2(img, ref) <= 1e-4
+    assert same_bits(img, ref)
+    for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples"):
+        assert st[k] == ost[k], k
+    # the uninstrumented kernel gives the same image
+    p.flags = 0
+    gpu_ctx.render(p)
+    assert same_bits(gpu_ctx.read_radiance(), img)
+
+
+def test_bvh4_wide_input_gives_same_hits(rt, orc, gpu_ctx):
+    # config C3: the BVH4_wide file of tests/test.cpp is a valid BVH input; closest hits agree
+    tris = rt.procedural_scene(0, 20000)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    bvh2 = gpu_ctx.read_bvh2()
+    wide = rt.bvh2_to_bvh4_wide(bvh2)
+    gpu_ctx.set_bvh4(wide)
+    cam, quat = CAMS[0]
+    gpu_ctx.render(gpu_ctx.make_params(160, 96, cam, quat, mode=rt.PT_MODE_REFERENCE))
+    img = gpu_ctx.read_radiance()
+    ref, _, _ = orc.render(orc.make_params(160, 96, tris.size // 9, cam, quat, mode=orc_mod.MODE_SINGLE), tris, wide)
+    assert same_bits(img, ref)
+
+
+def test_tile_sharding_matches_whole_frame(rt, gpu_ctx):
+    import ctypes as C
+    tris = rt.procedural_scene(0, 20000)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    w, h = 200, 120
+    kw = dict(mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=5)
+    gpu_ctx.render(gpu_ctx.make_params(w, h, **kw))
+    full = gpu_ctx.read_radiance().copy()
+    hip = C.CDLL("libamdhip64.so")
+    for count in (2, 3, 8):
+        stride = max(rt.tile_layout(w, h, r, count)[1] for r in range(count))
+        gathered = C.c_void_p()
+        assert hip.hipMalloc(C.byref(gathered), C.c_size_t(stride * 4 * count)) == 0
+        for r in range(count):
+            gpu_ctx.render(gpu_ctx.make_params(w, h, tile_rank=r, tile_count=count, **kw))
+            ptr, floats = gpu_ctx.compact_radiance()
+            gpu_ctx.synchronize()
+            assert hip.hipMemcpy(C.c_void_p(gathered.value + r * stride * 4), C.c_void_p(ptr), C.c_size_t(floats * 4), 3) == 0
+        gpu_ctx.deinterleave(gathered.value, stride, w, h, count)
+        got = gpu_ctx.read_radiance()
+        hip.hipFree(gathered)
+        assert same_bits(got, full), count
+
+
+def test_error_paths(rt, gpu_ctx):
+    fresh = rt.Context(0)
+    with pytest.raises(rt.PtError) as e:
+        fresh.num_tris = 0
+        fresh.render(fresh.make_params(8, 8))
+    assert e.value.code == 4                      # PT_ERR_NO_SCENE
+    fresh.set_triangles(TETRA)
+    fresh.build_bvh()
+    with pytest.raises(rt.PtError):
+        fresh.render(fresh.make_params(8, 8, num_tris=99))   # more than uploaded
+    bad = fresh.read_bvh4().copy()
+    bad[1 + 4] = 0                                # second child of the root points at the root: cycle
+    with pytest.raises(rt.PtError) as e2:
+        fresh.set_bvh4(bad)
+    assert e2.value.code == 5
+    fresh.close()
