@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+One *step* = one complete frame of the C2 workload: dragon-class procedural mesh (871,414
+triangles, the reference's dragon.glb is absent), native LBVH2 -> collapsed BVH4, 1920x1080,
+4 samples per pixel, 8 bounces, camera (0,0,2.5) / identity quaternion / FOV 70 deg
+(src/main.js:12, PathTracer.js:761).  value = Msamples/s = W*H*spp*K / wall time of the K
+timed steps (max over ranks), scene already resident in HBM.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): the frame is sharded by
+interleaved 8x8 pixel tiles (rank = (tx+ty) % N); each rank renders its tiles into a compact
+buffer, RCCL gathers the buffers on rank 0 over xGMI (torch.distributed backend "nccl"), rank 0
+de-interleaves them into the full frame.  The gather of frame i overlaps the render of frame
+i+1 (double-buffered).  Total work per step is fixed -> "scaling": "strong".
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SPP, BOUNCES, SEED = 1920, 1080, 4, 8, 1
+NUM_TRIS, SCENE_SEED = 871414, 20260109
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+BYTES_NODE, BYTES_TRI, BYTES_SAMPLE = 32, 36, 16
+
+
+def algorithmic_bytes(st):
+    return BYTES_NODE * st["nodes_examined"] + BYTES_TRI * st["tris_tested"] + BYTES_SAMPLE * st["samples"]
+
+
+def cpu_baseline(tris, bvh4):
+    """The CPU oracle (a port of the same loop) on a bounded sample of the same workload:
+    the whole frame, single thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc as orc_mod
+    orc = orc_mod.load()
+    p = orc.make_params(WIDTH, HEIGHT, NUM_TRIS, mode=orc_mod.MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED, step=(1, 1))
+    t0 = time.time()
+    _, _, st = orc.render(p, tris, bvh4)
+    dt = time.time() - t0
+    return {"value": round(st["samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "every pixel of the same 1920x1080/4spp/8-bounce frame (%d samples, %.1f s), oracle/pt_oracle.cpp single thread, %d host cores present"
+                      % (st["samples"], dt, os.cpu_count() or 0)}, st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch                     # first: its HIP runtime is the one libmi355pt binds to
+    import torch.distributed as dist
+    import numpy as np
+    rt = importlib.import_module("raytracer-public_amd")
+
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    device = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+
+    width, height = args.width, args.height
+    tris = rt.procedural_scene(rt.SCENE_DRAGON_CLASS, NUM_TRIS, SCENE_SEED)
+    ctx = rt.Context(device)
+    stream = torch.cuda.Stream(device=device)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.set_triangles(tris)
+    ctx.build_bvh()                  # Morton+sort, LBVH2 kernels, collapse: data/BVH2.bin equivalent
+
+    def params(stats=False):
+        return ctx.make_params(width, height, mode=rt.PT_MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED,
+                               tile_rank=rank, tile_count=world, stats=stats)
+
+    sharded = world > 1
+    if sharded:
+        stride = max(rt.tile_layout(width, height, r, world)[1] for r in range(world))
+        compact = [torch.zeros(stride, dtype=torch.float32, device="cuda") for _ in range(2)]
+        gathered = [torch.zeros(world, stride, dtype=torch.float32, device="cuda") for _ in range(2)] if rank == 0 else [None, None]
+        host_stage = backend != "nccl"   # rehearsal path (gloo): stage through host memory
+
+    # exact traversal counters of this rank's share of the frame (deterministic, same every step)
+    with torch.cuda.stream(stream):
+        if sharded:
+            ctx.set_compact_buffer(compact[0].data_ptr(), stride)
+        ctx.render(params(stats=True))
+        my_stats = ctx.stats()
+    my_bytes = algorithmic_bytes(my_stats)
+
+    pending = [None]
+
+    def finish(prev):
+        if prev is None:
+            return
+        work, slot = prev
+        work.wait()
+        if rank == 0:
+            if host_stage:
+                gathered[slot].copy_(torch.stack(work.cpu_list))
+            ctx.deinterleave(gathered[slot].data_ptr(), stride, width, height, world)
+
+    class _HostWork:                 # gloo rehearsal: synchronous host gather
+        def __init__(self, buf, slot):
+            stream.synchronize()
+            src = buf.cpu()
+            self.cpu_list = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+            dist.gather(src, self.cpu_list, dst=0)
+
+        def wait(self):
+            pass
+
+    def step(i, p):
+        with torch.cuda.stream(stream):
+            if not sharded:
+                ctx.render(p)
+                return
+            slot = i & 1
+            ctx.set_compact_buffer(compact[slot].data_ptr(), stride)
+            ctx.render(p)
+            if host_stage:
+                work = _HostWork(compact[slot], slot)
+            else:
+                glist = [gathered[slot][r] for r in range(world)] if rank == 0 else None
+                work = dist.gather(compact[slot], glist, dst=0, async_op=True)
+            finish(pending[0])           # gather(i-1) has had the whole render(i) to complete
+            pending[0] = (work, slot)
+
+    def drain():
+        with torch.cuda.stream(stream):
+            finish(pending[0])
+            pending[0] = None
+
+    p = params()
+    for i in range(args.warmup):
+        step(i, p)
+    drain()
+    if sharded:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.timing_begin(args.steps)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, p)
+    drain()
+    torch.cuda.synchronize()
+    if sharded:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ctx.timing_collect(args.steps)
+
+    if sharded:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        samples_per_step = width * height * SPP
+        value = samples_per_step * args.steps / elapsed / 1e6
+        k_avg_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
+        achieved = my_bytes / (k_avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # written from a rocprofv3 --pmc pass
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("bytes_per_launch_n%d" % world)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples/sec @1920x1080 Stanford-Dragon-class, 4 spp, 8 bounces",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: dragon-class procedural closed mesh (%d tris, seed %d; dragon.glb absent), native LBVH2->BVH4, %dx%d, %d spp, %d bounces, camera (0,0,2.5) identity quat FOV 70"
+                                   % (NUM_TRIS, SCENE_SEED, width, height, SPP, BOUNCES),
+                       "triangles": NUM_TRIS, "bvh4_nodes": ctx.scene_info()["numNodes4"], "width": width, "height": height,
+                       "spp": SPP, "max_bounces": BOUNCES, "seed": SEED,
+                       "sharding": ("interleaved 8x8 tiles over %d GPUs, RCCL gather to rank 0" % world) if sharded else "single GPU, whole frame"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "render_rays_kernel<PATH>", "kernel_avg_ms": round(k_avg_ms, 4),
+                         "algorithmic_bytes_per_launch": my_bytes,
+                         "counters": {k: my_stats[k] for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples")}},
+        }
+        if world == 1 and not args.no_cpu_baseline and (width, height) == (WIDTH, HEIGHT):
+            base, ost = cpu_baseline(tris, ctx.read_bvh4())
+            out["cpu_baseline"] = base
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,6 +150,12 @@ int pt_render(PtContext* ctx, const PtRenderParams* params);
 /* Device time of the last pt_render's kernel(s), by hipEvents on the stream it ran on.
  * Synchronises the stream. */
 int pt_last_render_ms(PtContext* ctx, float* ms);
+/* Per-launch kernel timing without host synchronisation inside a timed loop: after
+ * pt_timing_begin(ctx, capacity) every pt_render records its own hipEvent pair (on the stream
+ * the kernel is launched on) into a ring; pt_timing_collect synchronises once and returns the
+ * elapsed milliseconds of the recorded launches (oldest first) and their count. */
+int pt_timing_begin(PtContext* ctx, uint32_t capacity);
+int pt_timing_collect(PtContext* ctx, float* ms, uint32_t capacity, uint32_t* count);
 int pt_get_stats(PtContext* ctx, PtStats* out);
 /* Full-frame f32 RGBA W*H*4 (tile_count <= 1).  Synchronises. */
 int pt_read_radiance(PtContext* ctx, float* dst, uint64_t dst_floats);
@@ -167,6 +173,10 @@ int pt_tile_layout(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t
 /* Device pointer + size of this rank's compact radiance buffer (tile-major, 64 px per tile,
  * f32 RGBA) after a render with tile_count > 1: the send buffer of the RCCL gather. */
 int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats);
+/* Render tile-sharded frames straight into a caller-owned device buffer (e.g. a torch tensor
+ * that is then handed to the RCCL gather) instead of the context's own compact buffer.
+ * device_ptr = NULL restores the internal buffer.  `floats` is the buffer's capacity. */
+int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
 /* Rank 0: scatter `tile_count` gathered compact buffers (device memory, concatenated in rank
  * order, each padded to `stride_floats`) into the context's full-frame radiance buffer. */
 int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride_floats,

@@ -60,7 +60,10 @@ struct PtContext {
     uint32_t out_w = 0, out_h = 0;   // dimensions of the last full-frame result in d_out
     uint32_t accum_w = 0, accum_h = 0, accum_count = 0, accum_rank = 0;
     uint64_t compact_floats = 0;
+    float4* ext_compact = nullptr; uint64_t ext_compact_floats = 0;
     bool last_stats = false;
+    std::vector<hipEvent_t> ring;    // start/stop pairs recorded by pt_render while timing is on
+    uint32_t ring_used = 0;
 };
 
 namespace {
@@ -136,6 +139,7 @@ void pt_destroy(PtContext* ctx) {
     ctx->d_morton.release(); ctx->d_triidx.release(); ctx->d_parent.release(); ctx->d_flags.release();
     ctx->d_out.release(); ctx->d_accum.release(); ctx->d_compact.release(); ctx->d_compact_accum.release();
     ctx->d_tiles.release(); ctx->d_u32tmp.release(); ctx->d_stats.release();
+    for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -392,9 +396,14 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
             ctx->tiles_w = p->width; ctx->tiles_h = p->height; ctx->tiles_rank = p->tile_rank; ctx->tiles_count = count;
         }
         A.tiles = ctx->d_tiles.ptr; A.num_tiles = uint32_t(ctx->tiles_host.size());
-        PT_HIP(ctx, ctx->d_compact.ensure(size_t(A.num_tiles) * 64));
-        A.out = ctx->d_compact.ptr;
         ctx->compact_floats = uint64_t(A.num_tiles) * 64ull * 4ull;
+        if (ctx->ext_compact) {
+            if (ctx->ext_compact_floats < ctx->compact_floats) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: caller-owned compact buffer too small");
+            A.out = ctx->ext_compact;
+        } else {
+            PT_HIP(ctx, ctx->d_compact.ensure(size_t(A.num_tiles) * 64));
+            A.out = ctx->d_compact.ptr;
+        }
     } else {
         A.tiles = nullptr; A.num_tiles = A.tiles_x * tiles_y;
         PT_HIP(ctx, ctx->d_out.ensure(npx));
@@ -417,11 +426,39 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         A.stats = ctx->d_stats.ptr;
     }
     ctx->last_stats = stats;
-    PT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    const bool ring = ctx->ring_used + 2 <= ctx->ring.size();
+    hipEvent_t e0 = ring ? ctx->ring[ctx->ring_used] : ctx->ev_start, e1 = ring ? ctx->ring[ctx->ring_used + 1] : ctx->ev_stop;
+    PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
     const int kmode = p->mode == PT_MODE_REFERENCE_PACKET ? PT_KMODE_PACKET : (p->mode == PT_MODE_REFERENCE ? PT_KMODE_REFERENCE : PT_KMODE_PATH);
     PT_HIP(ctx, ptk::launch_render(A, kmode, stats, ctx->stream));
-    PT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
-    ctx->timed = true;
+    PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    if (ring) ctx->ring_used += 2;
+    ctx->timed = !ring;
+    return PT_OK;
+}
+
+int pt_timing_begin(PtContext* ctx, uint32_t capacity) {
+    if (int rc = bind(ctx)) return rc;
+    while (ctx->ring.size() < size_t(capacity) * 2) {
+        hipEvent_t e = nullptr;
+        PT_HIP(ctx, hipEventCreate(&e));
+        ctx->ring.push_back(e);
+    }
+    while (ctx->ring.size() > size_t(capacity) * 2) { (void)hipEventDestroy(ctx->ring.back()); ctx->ring.pop_back(); }
+    ctx->ring_used = 0;
+    return PT_OK;
+}
+
+int pt_timing_collect(PtContext* ctx, float* ms, uint32_t capacity, uint32_t* count) {
+    if (int rc = bind(ctx)) return rc;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t n = ctx->ring_used / 2;
+    uint32_t got = 0;
+    for (uint32_t i = 0; i < n && i < capacity; ++i, ++got)
+        PT_HIP(ctx, hipEventElapsedTime(&ms[i], ctx->ring[2 * i], ctx->ring[2 * i + 1]));
+    if (count) *count = got;
+    for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
+    ctx->ring.clear(); ctx->ring_used = 0;
     return PT_OK;
 }
 
@@ -481,10 +518,17 @@ int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t ds
     return PT_OK;
 }
 
+int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats) {
+    if (int rc = bind(ctx)) return rc;
+    ctx->ext_compact = (float4*)device_ptr;
+    ctx->ext_compact_floats = device_ptr ? floats : 0;
+    return PT_OK;
+}
+
 int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats) {
     if (int rc = bind(ctx)) return rc;
-    if (ctx->compact_floats == 0 || !ctx->d_compact.ptr) return fail(ctx, PT_ERR_NO_SCENE, "pt_compact_radiance: no tile-sharded render yet");
-    if (device_ptr) *device_ptr = ctx->d_compact.ptr;
+    if (ctx->compact_floats == 0 || !(ctx->ext_compact || ctx->d_compact.ptr)) return fail(ctx, PT_ERR_NO_SCENE, "pt_compact_radiance: no tile-sharded render yet");
+    if (device_ptr) *device_ptr = ctx->ext_compact ? (void*)ctx->ext_compact : (void*)ctx->d_compact.ptr;
     if (floats) *floats = ctx->compact_floats;
     return PT_OK;
 }

@@ -528,13 +528,13 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const float4* __restr
     const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
     if (px >= width || py >= height) return;
     const uint32_t rank = (tx + ty) % count;
-    // slot of (tx,ty) in its rank's row-major list: tiles of that rank in earlier rows + earlier in this row
-    uint32_t slot = 0;
-    // rows above: row r holds tiles with tx = (rank - r) mod count, stepping by count
-    // closed form per row: number of tx in [0,tiles_x) with (tx + r) % count == rank
-    for (uint32_t r = 0; r < ty; ++r) {
-        const uint32_t first = (rank + count - (r % count)) % count;
-        slot += (first < tiles_x) ? (tiles_x - first + count - 1) / count : 0u;
+    // slot of (tx,ty) in its rank's row-major list.  Row r holds the rank's tiles at
+    // tx = first(r), first(r)+count, ... with first(r) = (rank - r) mod count; over `count`
+    // consecutive rows first() takes every residue once, so such a block holds tiles_x tiles.
+    uint32_t slot = (ty / count) * tiles_x;
+    for (uint32_t r = ty - ty % count; r < ty; ++r) {
+        const uint32_t f = (rank + count - (r % count)) % count;
+        slot += (f < tiles_x) ? (tiles_x - f + count - 1) / count : 0u;
     }
     const uint32_t first = (rank + count - (ty % count)) % count;
     slot += (tx - first) / count;

@@ -1,0 +1,79 @@
+"""N > 1 path on CPU: two processes (torch.distributed, gloo) follow bench.py's protocol --
+rank = (tx+ty) % world tile ownership, compact tile-major buffers padded to a common stride,
+gather to rank 0, de-interleave -- with the CPU oracle standing in for the renderer.  The
+device-side equivalents (pt_render tile mode, pt_deinterleave) are covered bit-exactly on the
+GPU by tests/test_gpu_parity.py::test_tile_sharding_matches_whole_frame."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def owned_tiles(width, height, rank, world):
+    tx_n, ty_n = (width + 7) // 8, (height + 7) // 8
+    return [(tx, ty) for ty in range(ty_n) for tx in range(tx_n) if (tx + ty) % world == rank]
+
+
+def compact_from_full(full, rank, world, stride_floats):
+    h, w = full.shape[:2]
+    out = np.zeros(stride_floats, np.float32).reshape(-1, 64, 4)
+    for slot, (tx, ty) in enumerate(owned_tiles(w, h, rank, world)):
+        for lane in range(64):
+            px, py = tx * 8 + (lane & 7), ty * 8 + (lane >> 3)
+            if px < w and py < h:
+                out[slot, lane] = full[py, px]
+    return out.reshape(-1)
+
+
+def deinterleave(gathered, width, height, world):
+    full = np.zeros((height, width, 4), np.float32)
+    for rank in range(world):
+        buf = gathered[rank].reshape(-1, 64, 4)
+        for slot, (tx, ty) in enumerate(owned_tiles(width, height, rank, world)):
+            for lane in range(64):
+                px, py = tx * 8 + (lane & 7), ty * 8 + (lane >> 3)
+                if px < width and py < height:
+                    full[py, px] = buf[slot, lane]
+    return full
+
+
+def _worker(rank, world, port, width, height, result_path):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    import orc as orc_mod
+    from scenes import random_soup
+    rt = importlib.import_module("raytracer-public_amd")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    orc = orc_mod.load()
+    tris = random_soup(400, 3)
+    _, bvh4 = orc.build_bvh4(tris)
+    p = orc.make_params(width, height, 400, cam_pos=(0, 0, 2.2), mode=orc_mod.MODE_PATH, spp=1, max_bounces=2, seed=9)
+    full, _, _ = orc.render(p, tris, bvh4)          # every rank can compute any pixel: results are keyed by pixel, not by rank
+    stride = max(rt.tile_layout(width, height, r, world)[1] for r in range(world))
+    nt, fl = rt.tile_layout(width, height, rank, world)
+    assert nt == len(owned_tiles(width, height, rank, world)) and fl == nt * 256
+    mine = torch.from_numpy(compact_from_full(full, rank, world, stride))
+    glist = [torch.empty(stride) for _ in range(world)] if rank == 0 else None
+    work = dist.gather(mine, glist, dst=0, async_op=True)
+    work.wait()
+    if rank == 0:
+        got = deinterleave([g.numpy() for g in glist], width, height, world)
+        np.save(result_path, np.array([np.array_equal(got.view(np.uint32), full.view(np.uint32))]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("width,height", [(64, 40), (70, 33)])
+def test_two_rank_gather_reassembles_the_frame(tmp_path, width, height):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    result = str(tmp_path / "ok.npy")
+    mp.spawn(_worker, args=(2, port, width, height, result), nprocs=2, join=True)
+    assert bool(np.load(result)[0])
