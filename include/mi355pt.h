@@ -72,7 +72,8 @@ typedef struct PtRenderParams {
 } PtRenderParams;
 
 enum {
-    PT_FLAG_STATS = 1u           /* run the instrumented kernel variant and fill PtStats */
+    PT_FLAG_STATS = 1u,          /* run the instrumented kernel variant and fill PtStats */
+    PT_FLAG_SIMPLE_KERNEL = 2u   /* PT_MODE_PATH: one-pixel-per-lane kernel instead of the persistent megakernel (A/B checks) */
 };
 
 /* Traversal counters of the last PT_FLAG_STATS render (algorithmic-bytes bookkeeping,

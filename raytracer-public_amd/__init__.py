@@ -21,6 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libmi355pt.so")
 
 PT_MODE_REFERENCE_PACKET, PT_MODE_REFERENCE, PT_MODE_PATH = 0, 1, 2
 PT_FLAG_STATS = 1
+PT_FLAG_SIMPLE_KERNEL = 2
 SCENE_DRAGON_CLASS, SCENE_SPONZA_CLASS = 0, 1
 
 
@@ -225,7 +226,7 @@ class Context:
         return out
 
     def make_params(self, width, height, cam_pos=(0, 0, 2.5), cam_quat=(0, 0, 0, 1), mode=PT_MODE_REFERENCE, spp=1,
-                    max_bounces=0, seed=1, frame=0, accumulate=False, tile_rank=0, tile_count=1, stats=False, num_tris=None):
+                    max_bounces=0, seed=1, frame=0, accumulate=False, tile_rank=0, tile_count=1, stats=False, num_tris=None, simple_kernel=False):
         p = PtRenderParams()
         p.width, p.height = width, height
         p.focal, p.aspect = focal_aspect(width, height)
@@ -235,7 +236,7 @@ class Context:
         p.frame, p.mode, p.spp, p.max_bounces, p.seed = frame, mode, spp, max_bounces, seed
         p.accumulate = 1 if accumulate else 0
         p.tile_rank, p.tile_count = tile_rank, tile_count
-        p.flags = PT_FLAG_STATS if stats else 0
+        p.flags = (PT_FLAG_STATS if stats else 0) | (PT_FLAG_SIMPLE_KERNEL if simple_kernel else 0)
         return p
 
     def render(self, params):

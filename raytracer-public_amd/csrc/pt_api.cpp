@@ -54,7 +54,10 @@ struct PtContext {
 
     // frame
     DevBuf<float4> d_out, d_accum, d_compact, d_compact_accum;
-    DevBuf<uint32_t> d_tiles, d_u32tmp;
+    DevBuf<uint32_t> d_tiles, d_u32tmp, d_queue;
+    DevBuf<float4> d_samples;
+    DevBuf<uint2> d_spill;
+    int num_cus = 0;
     DevBuf<unsigned long long> d_stats;
     std::vector<uint32_t> tiles_host; uint32_t tiles_w = 0, tiles_h = 0, tiles_rank = 0, tiles_count = 0;
     uint32_t out_w = 0, out_h = 0;   // dimensions of the last full-frame result in d_out
@@ -125,6 +128,8 @@ int pt_create(int device_ordinal, PtContext** out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop);
     if (e == hipSuccess) e = ctx->d_stats.ensure(8);
+    if (e == hipSuccess) e = ctx->d_queue.ensure(16);
+    if (e == hipSuccess) { hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, dev); if (e == hipSuccess) ctx->num_cus = prop.multiProcessorCount; }
     if (e != hipSuccess) { int rc = fail_hip(nullptr, e, "pt_create"); pt_destroy(ctx); return rc; }
     ctx->stream = ctx->own_stream;
     *out = ctx;
@@ -139,6 +144,7 @@ void pt_destroy(PtContext* ctx) {
     ctx->d_morton.release(); ctx->d_triidx.release(); ctx->d_parent.release(); ctx->d_flags.release();
     ctx->d_out.release(); ctx->d_accum.release(); ctx->d_compact.release(); ctx->d_compact_accum.release();
     ctx->d_tiles.release(); ctx->d_u32tmp.release(); ctx->d_stats.release();
+    ctx->d_queue.release(); ctx->d_samples.release(); ctx->d_spill.release();
     for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -428,10 +434,25 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     ctx->last_stats = stats;
     const bool ring = ctx->ring_used + 2 <= ctx->ring.size();
     hipEvent_t e0 = ring ? ctx->ring[ctx->ring_used] : ctx->ev_start, e1 = ring ? ctx->ring[ctx->ring_used + 1] : ctx->ev_stop;
-    PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
     const int kmode = p->mode == PT_MODE_REFERENCE_PACKET ? PT_KMODE_PACKET : (p->mode == PT_MODE_REFERENCE ? PT_KMODE_REFERENCE : PT_KMODE_PATH);
-    PT_HIP(ctx, ptk::launch_render(A, kmode, stats, ctx->stream));
-    PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    if (kmode == PT_KMODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL)) {
+        const uint32_t grid = uint32_t(ctx->num_cus > 0 ? ctx->num_cus : 256) * uint32_t(ptk::megakernel_blocks_per_cu());
+        A.num_batches = A.num_tiles * p->spp;
+        A.perm_cols = (A.num_batches + 63u) / 64u;
+        A.total_items = A.perm_cols * 64u * 64u;
+        A.chunk_items = 256u;
+        PT_HIP(ctx, ctx->d_samples.ensure(size_t(A.num_batches) * 64u));
+        PT_HIP(ctx, ctx->d_spill.ensure(size_t(grid) * 256u * size_t(64 - PT_SHORT_STACK)));
+        A.samples = ctx->d_samples.ptr; A.queue = ctx->d_queue.ptr; A.spill = ctx->d_spill.ptr;
+        // timing ring: events tightly around the dominant kernel; otherwise around the whole pass
+        if (!ring) PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+        PT_HIP(ctx, ptk::launch_megakernel(A, stats, grid, ctx->stream, ring ? e0 : nullptr, ring ? e1 : nullptr));
+        if (!ring) PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    } else {
+        PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+        PT_HIP(ctx, ptk::launch_render(A, kmode, stats, ctx->stream));
+        PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    }
     if (ring) ctx->ring_used += 2;
     ctx->timed = !ring;
     return PT_OK;

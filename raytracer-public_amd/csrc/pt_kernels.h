@@ -7,6 +7,20 @@
 #define PT_KMODE_REFERENCE 1
 #define PT_KMODE_PATH      2
 
+// megakernel tuning knobs (overridable with -D at build time)
+#ifndef PT_SHORT_STACK
+#define PT_SHORT_STACK 16          // LDS stack entries per lane (8 B each); deeper entries spill to global scratch
+#endif
+#ifndef PT_MEGA_WAVES_PER_SIMD
+#define PT_MEGA_WAVES_PER_SIMD 5   // resident 256-thread blocks per CU = waves per SIMD
+#endif
+#ifndef PT_SHADE_THRESHOLD
+#define PT_SHADE_THRESHOLD 16      // shade when this many lanes of a wavefront wait with a finished ray
+#endif
+#ifndef PT_FILL_THRESHOLD
+#define PT_FILL_THRESHOLD 16       // regenerate when this many lanes of a wavefront are without a path
+#endif
+
 namespace ptk {
 
 // Passed by value as the kernel argument (lives in SGPRs / the kernarg segment).
@@ -33,9 +47,18 @@ struct RenderArgs {
     uint32_t root_ref; uint32_t root_box[3]; uint32_t root_degenerate;
     // extension
     uint32_t spp, max_bounces, seed, accumulate, compact;
+    // persistent megakernel
+    float4*   samples;          // per-sample radiance, item = (slot*spp + s)*64 + lane_in_tile
+    uint32_t* queue;            // global item cursor
+    uint2*    spill;            // deep stack entries: [entry][grid lane]
+    uint32_t  total_items, chunk_items;   // logical items (64*64*perm_cols) and items per queue claim
+    uint32_t  num_batches, perm_cols;     // real (tile,sample) batches; columns of the 64-row batch transpose
 };
 
 hipError_t launch_render(const RenderArgs& args, int kmode, bool stats, hipStream_t stream);
+// k0/k1 (optional): events recorded immediately around the dominant trace_paths_kernel
+hipError_t launch_megakernel(const RenderArgs& args, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1);
+int megakernel_blocks_per_cu();
 hipError_t launch_lbvh2(uint32_t* bvh2, const float* tris9, const uint32_t* morton, const uint32_t* tri_index,
                         uint32_t* parent, uint32_t* flags, uint32_t num_tris, hipStream_t stream);
 hipError_t launch_deinterleave(const float4* gathered, uint64_t stride_px, float4* full, uint32_t width, uint32_t height,

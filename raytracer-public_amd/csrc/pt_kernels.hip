@@ -13,70 +13,9 @@
 #include <stdint.h>
 
 #include "pt_kernels.h"
+#include "pt_device.h"
 
 namespace ptk {
-
-// ------------------------------------------------------------------------------------
-// small vector helpers (explicit operation order, never contracted)
-// ------------------------------------------------------------------------------------
-struct F3 { float x, y, z; };
-__device__ __forceinline__ F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ float dot3(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ F3 cross3(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-__device__ __forceinline__ F3 normalize3(F3 v) { const float inv = 1.0f / sqrtf(dot3(v, v)); return v * inv; }
-// WGSL min/max on non-NaN data (sign of zero never reaches a comparison result)
-__device__ __forceinline__ float wmin(float a, float b) { return (b < a) ? b : a; }
-__device__ __forceinline__ float wmax(float a, float b) { return (b > a) ? b : a; }
-
-__device__ __forceinline__ float half_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
-__device__ __forceinline__ float half_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
-
-constexpr float kInfT = 1e30f;          // renderer.wgsl:64
-constexpr float kTriEps = 1e-7f;        // renderer.wgsl:178
-constexpr uint32_t kLeaf = 0x80000000u;
-constexpr uint32_t kInvalidRef = 0xFFFFFFFFu;
-constexpr int kStackMax = 64;           // renderer.wgsl:8
-
-struct Ray { F3 o, d, inv; };
-
-__device__ __forceinline__ F3 safe_inv(F3 d) {      // renderer.wgsl:74-80
-    return f3(fabsf(d.x) > 1e-8f ? 1.0f / d.x : kInfT,
-              fabsf(d.y) > 1e-8f ? 1.0f / d.y : kInfT,
-              fabsf(d.z) > 1e-8f ? 1.0f / d.z : kInfT);
-}
-
-__device__ __forceinline__ F3 rotate_quat(F3 v, const float* q) {   // renderer.wgsl:66-72
-    const F3 u = f3(q[0], q[1], q[2]); const float s = q[3];
-    const F3 uv = cross3(u, v), uuv = cross3(u, uv);
-    return f3(__builtin_fmaf(2.0f, __builtin_fmaf(s, uv.x, uuv.x), v.x),
-              __builtin_fmaf(2.0f, __builtin_fmaf(s, uv.y, uuv.y), v.y),
-              __builtin_fmaf(2.0f, __builtin_fmaf(s, uv.z, uuv.z), v.z));
-}
-
-__device__ __forceinline__ Ray primary_ray(const RenderArgs& A, float fx, float fy) {   // renderer.wgsl:387-395
-    const float uvx = fx / (float)A.width, uvy = fy / (float)A.height;
-    const float px = __builtin_fmaf(uvx, 2.0f, -1.0f), py = __builtin_fmaf(uvy, 2.0f, -1.0f);
-    Ray r;
-    r.d = rotate_quat(normalize3(f3(px * A.aspect, py, -A.focal)), A.quat);
-    r.o = f3(A.cam[0], A.cam[1], A.cam[2]);
-    r.inv = safe_inv(r.d);
-    return r;
-}
-
-// slab test of one packed f16 box (renderer.wgsl:147-159); returns hit, writes tmin
-__device__ __forceinline__ bool slab(const Ray& r, uint32_t w0, uint32_t w1, uint32_t w2, float best, float& tmin_out) {
-    const F3 mn = f3(half_lo(w0), half_hi(w0), half_lo(w1));
-    const F3 mx = f3(half_hi(w1), half_lo(w2), half_hi(w2));
-    const F3 t1 = (mn - r.o) * r.inv, t2 = (mx - r.o) * r.inv;
-    const float tmin = wmax(wmax(wmin(t1.x, t2.x), wmin(t1.y, t2.y)), wmin(t1.z, t2.z));
-    const float tmax = wmin(wmin(wmax(t1.x, t2.x), wmax(t1.y, t2.y)), wmax(t1.z, t2.z));
-    tmin_out = tmin;
-    return (tmax >= wmax(tmin, 0.0f)) && (tmin < best);
-}
 
 struct Counters { uint32_t nodes, tris, drops, maxstack; };
 
@@ -163,59 +102,6 @@ __device__ __forceinline__ bool traverse(const RenderArgs& A, const Ray& r, floa
         }
     }
     return best_tri != kInvalidRef;
-}
-
-// ---- build-defined sampling; integer hash + fixed fmaf polynomials ----
-__device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
-__device__ __forceinline__ uint32_t sample_key(uint32_t seed, uint32_t pixel, uint32_t sidx) {
-    uint32_t h = mix32(seed + 0x9E3779B9u);
-    h = mix32(h ^ pixel);
-    return mix32(h ^ sidx);
-}
-__device__ __forceinline__ float rnd(uint32_t key, uint32_t bounce, uint32_t dim) {
-    const uint32_t h = mix32(key ^ (bounce * 8u + dim + 1u) * 0x9E3779B1u);
-    return (float)(h >> 8) * (1.0f / 16777216.0f);
-}
-__device__ __forceinline__ void sincos_2pi(float u, float& c, float& s) {
-    const float q = u * 4.0f;
-    const float kf = floorf(q + 0.5f);
-    const float y = (q - kf) * 1.57079632679489662f;
-    const float y2 = y * y;
-    float sp = __builtin_fmaf(y2, 2.7557319e-6f, -1.9841270e-4f);
-    sp = __builtin_fmaf(y2, sp, 8.3333333e-3f);
-    sp = __builtin_fmaf(y2, sp, -1.6666667e-1f);
-    sp = __builtin_fmaf(y2, sp, 1.0f);
-    const float sy = y * sp;
-    float cp = __builtin_fmaf(y2, -2.7557319e-7f, 2.4801587e-5f);
-    cp = __builtin_fmaf(y2, cp, -1.3888889e-3f);
-    cp = __builtin_fmaf(y2, cp, 4.1666667e-2f);
-    cp = __builtin_fmaf(y2, cp, -0.5f);
-    const float cy = __builtin_fmaf(y2, cp, 1.0f);
-    const int k = (int)kf & 3;
-    c = (k == 0) ? cy : (k == 1) ? -sy : (k == 2) ? -cy : sy;
-    s = (k == 0) ? sy : (k == 1) ? cy : (k == 2) ? -sy : -cy;
-}
-__device__ __forceinline__ F3 cosine_dir(F3 n, float u1, float u2) {
-    float c, s; sincos_2pi(u2, c, s);
-    const float r = sqrtf(u1);
-    const float lx = r * c, ly = r * s, lz = sqrtf(1.0f - u1);
-    const float sign = copysignf(1.0f, n.z);
-    const float a = -1.0f / (sign + n.z);
-    const float b = n.x * n.y * a;
-    const F3 t = f3(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
-    const F3 bt = f3(b, sign + n.y * n.y * a, -n.y);
-    return (t * lx + bt * ly) + n * lz;
-}
-
-constexpr float kEpsOrigin = 1e-4f;
-constexpr float kBgPrimary = 0.01f;    // renderer.wgsl:410
-constexpr float kSkyAmbient = 0.15f;   // renderer.wgsl:352
-constexpr uint32_t kRRStart = 2;
-
-__device__ __forceinline__ F3 light_dir() { return normalize3(f3(1.0f, 1.5f, 1.0f)); }   // renderer.wgsl:349
-__device__ __forceinline__ F3 tri_normal(const RenderArgs& A, uint32_t ti) {
-    const float4 c = A.tris[(size_t)ti * 3 + 2];
-    return f3(c.y, c.z, c.w);
 }
 
 // One work item = one pixel.  A wavefront owns one 8x8 tile (lane = y*8+x inside the tile).

@@ -1,0 +1,318 @@
+// pt_megakernel.hip -- the production form of the hot path for PT_MODE_PATH on gfx950:
+// a persistent-wavefront traversal + shade megakernel.
+//
+//   * work item = one pixel-sample; items are claimed in chunks from a global queue
+//     (one atomic per chunk and wave), so the grid is sized to the chip, not to the frame;
+//   * every lane is a small state machine  IDLE -> TRAVERSE -> DONE -> (TRAVERSE | IDLE):
+//     lanes whose path ended are refilled with new samples (ray regeneration), lanes whose
+//     ray ended wait until enough of the wavefront is waiting (__ballot / popcount) and are
+//     shaded together -- this is the wavefront-level compaction that keeps the 64 lanes busy
+//     across bounces although only ~13 % of the camera rays hit anything;
+//   * the traversal stack is a per-wavefront LDS short stack (kShort entries per lane, 8 B
+//     each, bank-conflict-free by construction) that spills its rare deep entries to a global
+//     scratch area, keeping the reference's 64-entry semantics;
+//   * per-sample radiance goes to a sample buffer; resolve_kernel sums the samples of a pixel
+//     in sample order (deterministic, bit-identical to the oracle) and applies accumulation.
+//
+// Traversal order, tie-breaking and arithmetic are exactly those of render_rays_kernel /
+// DESIGN.md sections 3-6 (the oracle checks both kernels bit-for-bit).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_kernels.h"
+#include "pt_device.h"
+
+namespace ptk {
+
+constexpr int kShort = PT_SHORT_STACK;    // LDS entries per lane
+constexpr uint32_t kPhaseIdle = 0, kPhaseTrav = 1, kPhaseDone = 2;
+
+struct Lane {
+    // ray
+    F3 o, d, inv;
+    float best_t; uint32_t best_tri;
+    uint32_t cur; int sp;
+    // path
+    F3 T, rad;
+    F3 d_next, contrib;
+    uint32_t key, item;
+    uint32_t bounce;      // bits 0..15 bounce index, bit 16 = current ray is a shadow ray, bit 17 = path continues after the shadow ray
+};
+
+constexpr uint32_t kShadowBit = 1u << 16, kContBit = 1u << 17;
+
+template <bool STATS>
+__global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kernel(const RenderArgs A) {
+    __shared__ uint2 lds_stack[4][kShort][64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint2* const stk = &lds_stack[wave][0][lane];                       // entry i at stk[i * 64]
+    uint2* const spill = A.spill + ((size_t)blockIdx.x * 256u + threadIdx.x);   // entry j at spill[j * spill_stride]
+    const size_t spill_stride = (size_t)gridDim.x * 256u;
+
+    const F3 base = f3(0.9f, 0.7f, 0.3f);
+    const F3 L = light_dir();
+    const F3 invL = safe_inv(L);
+    const bool scene_empty = (A.root_ref == kInvalidRef) || (A.num_tris == 0u) || (A.root_degenerate != 0u);
+
+    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: this wave's private item range
+    bool queue_empty = false;                 // wave-uniform
+
+    Lane S;
+    uint32_t phase = kPhaseIdle;
+    S.sp = 0; S.cur = 0; S.best_t = kInfT; S.best_tri = kInvalidRef; S.bounce = 0; S.key = 0; S.item = 0;
+    S.o = S.d = S.inv = S.T = S.rad = S.d_next = S.contrib = f3(0, 0, 0);
+    uint32_t c_nodes = 0, c_tris = 0, c_drops = 0, c_maxstack = 0, c_closest = 0, c_shadow = 0, c_samples = 0;
+
+    // ---- helpers as lambdas (all inlined) -------------------------------------------------
+    auto push = [&](uint32_t ref, float tmin) {
+        if (S.sp < kStackMax) {
+            const uint2 e = make_uint2(ref, __float_as_uint(tmin));
+            if (S.sp < kShort) stk[S.sp * 64] = e; else spill[(size_t)(S.sp - kShort) * spill_stride] = e;
+            ++S.sp;
+        } else if (STATS) ++c_drops;
+    };
+    // start a ray from S.o / S.d / S.inv: root box test; returns false when it misses outright
+    auto begin_ray = [&]() -> bool {
+        S.best_t = kInfT; S.best_tri = kInvalidRef; S.sp = 0;
+        if (scene_empty) return false;
+        if (STATS) { c_nodes += 1; if (c_maxstack < 1u) c_maxstack = 1u; }
+        Ray r; r.o = S.o; r.d = S.d; r.inv = S.inv;
+        float troot;
+        if (!slab(r, A.root_box[0], A.root_box[1], A.root_box[2], kInfT, troot)) return false;
+        S.cur = A.root_ref;
+        return true;
+    };
+
+    for (;;) {
+        // ------------------------------------------------------------------ shade DONE lanes
+        {
+            const unsigned long long m_done = __ballot(phase == kPhaseDone);
+            const unsigned long long m_trav = __ballot(phase == kPhaseTrav);
+            if (m_done != 0ull && (__popcll(m_done) >= PT_SHADE_THRESHOLD || m_trav == 0ull)) {
+                if (phase == kPhaseDone) {
+                    const bool hit = S.best_tri != kInvalidRef;
+                    const uint32_t bounce = S.bounce & 0xffffu;
+                    bool finish = false, launch = false;
+                    if (S.bounce & kShadowBit) {
+                        if (!hit) S.rad = S.rad + S.contrib;
+                        if (S.bounce & kContBit) { S.d = S.d_next; S.inv = safe_inv(S.d); S.bounce = bounce + 1u; launch = true; }
+                        else finish = true;
+                    } else if (!hit) {
+                        S.rad = S.rad + S.T * ((bounce == 0u) ? kBgPrimary : kSkyAmbient);
+                        finish = true;
+                    } else {
+                        const F3 n = tri_normal(A, S.best_tri);
+                        const F3 hp = S.o + S.d * S.best_t;
+                        const F3 nf = (dot3(n, S.d) < 0.0f) ? n : f3(-n.x, -n.y, -n.z);
+                        const F3 so = hp + nf * kEpsOrigin;
+                        const float ndl = dot3(nf, L);
+                        S.contrib = (S.T * base) * ndl;
+                        bool cont = bounce < A.max_bounces;
+                        if (cont) {
+                            F3 Tn = S.T * base;
+                            if (bounce >= kRRStart) {
+                                const float p = wmax(wmax(Tn.x, Tn.y), Tn.z);
+                                if (rnd(S.key, bounce, 4) >= p) cont = false;
+                                else Tn = Tn * (1.0f / p);
+                            }
+                            if (cont) { S.T = Tn; S.d_next = cosine_dir(nf, rnd(S.key, bounce, 2), rnd(S.key, bounce, 3)); }
+                        }
+                        S.o = so;
+                        if (ndl > 0.0f) {
+                            S.d = L; S.inv = invL;
+                            S.bounce = bounce | kShadowBit | (cont ? kContBit : 0u);
+                            launch = true;
+                        } else if (cont) {
+                            S.d = S.d_next; S.inv = safe_inv(S.d); S.bounce = bounce + 1u; launch = true;
+                        } else finish = true;
+                    }
+                    if (launch) {
+                        if (STATS) { if (S.bounce & kShadowBit) ++c_shadow; else ++c_closest; }
+                        phase = begin_ray() ? kPhaseTrav : kPhaseDone;   // a root miss is shaded on the next pass
+                    }
+                    if (finish) {
+                        A.samples[S.item] = make_float4(S.rad.x, S.rad.y, S.rad.z, 1.0f);
+                        phase = kPhaseIdle;
+                    }
+                }
+            }
+        }
+        // ------------------------------------------------------------------ refill IDLE lanes
+        {
+            const unsigned long long m_idle = __ballot(phase == kPhaseIdle);
+            const unsigned long long m_trav = __ballot(phase == kPhaseTrav);
+            if (m_idle != 0ull && !queue_empty && (__popcll(m_idle) >= PT_FILL_THRESHOLD || m_trav == 0ull)) {
+                const uint32_t want = (uint32_t)__popcll(m_idle);
+                if (chunk_end - chunk_next < want && chunk_next == chunk_end) {
+                    // claim a new chunk (one atomic per wave and chunk)
+                    uint32_t start = 0;
+                    if (lane == 0) start = atomicAdd(A.queue, A.chunk_items);
+                    start = __builtin_amdgcn_readfirstlane(start);
+                    if (start >= A.total_items) { queue_empty = true; }
+                    else { chunk_next = start; chunk_end = min(start + A.chunk_items, A.total_items); }
+                }
+                if (!queue_empty) {
+                    const uint32_t rank = (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull));
+                    const uint32_t avail = chunk_end - chunk_next;
+                    if (phase == kPhaseIdle && rank < avail) {
+                        // logical item -> batch permutation: 64 consecutive logical items are one
+                        // (tile, sample) batch; consecutive logical batches are perm_cols batches apart in
+                        // image order, so every claimed chunk holds the frame's average mix of hits and misses
+                        const uint32_t logical = chunk_next + rank;
+                        const uint32_t lb = logical >> 6;
+                        const uint32_t q = (lb & 63u) * A.perm_cols + (lb >> 6);
+                        const bool in_range = q < A.num_batches;
+                        const uint32_t item = q * 64u + (logical & 63u);
+                        const uint32_t p = item & 63u;
+                        const uint32_t s = q % A.spp, slot = in_range ? q / A.spp : 0u;
+                        const uint32_t tile = A.tiles ? A.tiles[slot] : slot;
+                        const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+                        const uint32_t px = tx * 8u + (p & 7u), py = ty * 8u + (p >> 3);
+                        if (in_range && px < A.width && py < A.height) {
+                            const uint32_t key = sample_key(A.seed, py * A.width + px, A.frame * A.spp + s);
+                            const Ray r = primary_ray(A, (float)px + rnd(key, 0, 0), (float)py + rnd(key, 0, 1));
+                            S.o = r.o; S.d = r.d; S.inv = r.inv;
+                            S.key = key; S.item = item; S.bounce = 0u;
+                            S.T = f3(1.0f, 1.0f, 1.0f); S.rad = f3(0.0f, 0.0f, 0.0f);
+                            if (STATS) { ++c_closest; ++c_samples; }
+                            if (begin_ray()) phase = kPhaseTrav;
+                            else {
+                                // camera ray misses the root box: rad = 0 + 1 * 0.01
+                                const F3 rr = S.rad + S.T * kBgPrimary;
+                                A.samples[item] = make_float4(rr.x, rr.y, rr.z, 1.0f);
+                            }
+                        }
+                    }
+                    chunk_next += min(want, avail);
+                }
+            }
+        }
+        // ------------------------------------------------------------------ exit / idle-spin
+        const unsigned long long m_trav = __ballot(phase == kPhaseTrav);
+        if (m_trav == 0ull) {
+            const unsigned long long m_done = __ballot(phase == kPhaseDone);
+            if (m_done == 0ull && queue_empty) break;
+            continue;
+        }
+        // ------------------------------------------------------------------ one traversal step
+        if (phase == kPhaseTrav) {
+            bool need_pop = false;
+            Ray r; r.o = S.o; r.d = S.d; r.inv = S.inv;
+            if (S.cur & kLeaf) {
+                const uint32_t ti = S.cur & 0x7fffffffu;
+                if (ti < A.num_tris) {
+                    const float4* tp = A.tris + (size_t)ti * 3;
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    if (STATS) ++c_tris;
+                    const F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
+                    const F3 pv = cross3(r.d, e2);
+                    const float det = dot3(e1, pv);
+                    if (!(fabsf(det) < kTriEps)) {
+                        const float inv_det = 1.0f / det;
+                        const F3 sv = r.o - v0;
+                        const float u = inv_det * dot3(sv, pv);
+                        if (!(u < 0.0f || u > 1.0f)) {
+                            const F3 q = cross3(sv, e1);
+                            const float v = inv_det * dot3(r.d, q);
+                            if (!(v < 0.0f || (u + v) > 1.0f)) {
+                                const float t = inv_det * dot3(e2, q);
+                                if (t > kTriEps && t < S.best_t) {
+                                    S.best_t = t; S.best_tri = ti;
+                                    if (S.bounce & kShadowBit) phase = kPhaseDone;   // any-hit: first accepted hit ends the ray
+                                }
+                            }
+                        }
+                    }
+                }
+                need_pop = true;
+            } else {
+                const uint4* np = A.nodes + (size_t)S.cur * 4;
+                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                float t0, t1, t2, t3;
+                const bool h0 = (n3.x != kInvalidRef) && slab(r, n0.x, n0.y, n0.z, S.best_t, t0);
+                const bool h1 = (n3.y != kInvalidRef) && slab(r, n0.w, n1.x, n1.y, S.best_t, t1);
+                const bool h2 = (n3.z != kInvalidRef) && slab(r, n1.z, n1.w, n2.x, S.best_t, t2);
+                const bool h3 = (n3.w != kInvalidRef) && slab(r, n2.y, n2.z, n2.w, S.best_t, t3);
+                if (STATS) c_nodes += (n3.x != kInvalidRef) + (n3.y != kInvalidRef) + (n3.z != kInvalidRef) + (n3.w != kInvalidRef);
+                int nslot = -1, fslot = -1; float tn = kInfT, tf = 0.0f; uint32_t rn = kInvalidRef, rf = kInvalidRef;
+                if (h0) { nslot = 0; tn = t0; rn = n3.x; fslot = 0; tf = t0; rf = n3.x; }
+                if (h1) { if (nslot < 0 || t1 < tn) { nslot = 1; tn = t1; rn = n3.y; } if (fslot < 0) { fslot = 1; tf = t1; rf = n3.y; } }
+                if (h2) { if (nslot < 0 || t2 < tn) { nslot = 2; tn = t2; rn = n3.z; } if (fslot < 0) { fslot = 2; tf = t2; rf = n3.z; } }
+                if (h3) { if (nslot < 0 || t3 < tn) { nslot = 3; tn = t3; rn = n3.w; } if (fslot < 0) { fslot = 3; tf = t3; rf = n3.w; } }
+                if (nslot < 0) need_pop = true;
+                else {
+                    if (h3) { if (nslot == 3) { if (fslot != 3) push(rf, tf); } else if (fslot != 3) push(n3.w, t3); }
+                    if (h2) { if (nslot == 2) { if (fslot != 2) push(rf, tf); } else if (fslot != 2) push(n3.z, t2); }
+                    if (h1) { if (nslot == 1) { if (fslot != 1) push(rf, tf); } else if (fslot != 1) push(n3.y, t1); }
+                    if (STATS) { if ((uint32_t)(S.sp + 1) > c_maxstack) c_maxstack = (uint32_t)(S.sp + 1); }
+                    if (S.sp < kStackMax) S.cur = rn;
+                    else { need_pop = true; if (STATS) ++c_drops; }
+                }
+            }
+            if (need_pop && phase == kPhaseTrav) {
+                bool found = false;
+                while (S.sp > 0) {
+                    --S.sp;
+                    const uint2 e = (S.sp < kShort) ? stk[S.sp * 64] : spill[(size_t)(S.sp - kShort) * spill_stride];
+                    if (__uint_as_float(e.y) < S.best_t) { S.cur = e.x; found = true; break; }
+                }
+                if (!found) phase = kPhaseDone;
+            }
+        }
+    }
+    if (STATS) {
+        atomicAdd(&A.stats[0], (unsigned long long)c_closest);
+        atomicAdd(&A.stats[1], (unsigned long long)c_shadow);
+        atomicAdd(&A.stats[2], (unsigned long long)c_nodes);
+        atomicAdd(&A.stats[3], (unsigned long long)c_tris);
+        atomicAdd(&A.stats[4], (unsigned long long)c_drops);
+        atomicMax(&A.stats[5], (unsigned long long)c_maxstack);
+        atomicAdd(&A.stats[6], (unsigned long long)c_samples);
+    }
+}
+
+// Sum the samples of each owned pixel in sample order; carry the running sum when accumulating.
+__global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = idx >> 6, p = idx & 63u;
+    if (slot >= A.num_tiles) return;
+    const uint32_t tile = A.tiles ? A.tiles[slot] : slot;
+    const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+    const uint32_t px = tx * 8u + (p & 7u), py = ty * 8u + (p >> 3);
+    if (px >= A.width || py >= A.height) return;
+    const size_t out_index = A.compact ? (size_t)idx : ((size_t)py * A.width + px);
+    F3 sum = f3(0.0f, 0.0f, 0.0f);
+    for (uint32_t s = 0; s < A.spp; ++s) {
+        const float4 v = A.samples[((size_t)slot * A.spp + s) * 64u + p];
+        sum = sum + f3(v.x, v.y, v.z);
+    }
+    float count = (float)A.spp;
+    if (A.accum) {
+        const float4 acc = A.accumulate ? A.accum[out_index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        sum = f3(acc.x + sum.x, acc.y + sum.y, acc.z + sum.z);
+        count = acc.w + count;
+        A.accum[out_index] = make_float4(sum.x, sum.y, sum.z, count);
+    }
+    const float inv = 1.0f / count;
+    A.out[out_index] = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, 1.0f);
+}
+
+hipError_t launch_megakernel(const RenderArgs& A, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1) {
+    hipError_t e = hipMemsetAsync(A.queue, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    if (A.total_items != 0u) {
+        if (k0) { e = hipEventRecord(k0, stream); if (e != hipSuccess) return e; }
+        if (stats) hipLaunchKernelGGL((trace_paths_kernel<true>), dim3(grid_blocks), dim3(256), 0, stream, A);
+        else       hipLaunchKernelGGL((trace_paths_kernel<false>), dim3(grid_blocks), dim3(256), 0, stream, A);
+        e = hipGetLastError(); if (e != hipSuccess) return e;
+        if (k1) { e = hipEventRecord(k1, stream); if (e != hipSuccess) return e; }
+        const uint32_t n = A.num_tiles * 64u;
+        hipLaunchKernelGGL(resolve_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, A);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+int megakernel_blocks_per_cu() { return PT_MEGA_WAVES_PER_SIMD; }
+
+} // namespace ptk

@@ -114,6 +114,13 @@ def test_path_mode_bit_exact(rt, orc, gpu_ctx, kind, spp, bounces):
     p.flags = 0
     gpu_ctx.render(p)
     assert same_bits(gpu_ctx.read_radiance(), img)
+    # ... and so does the one-pixel-per-lane kernel (second, independent HIP implementation), counters included
+    p.flags = rt.PT_FLAG_SIMPLE_KERNEL | rt.PT_FLAG_STATS
+    gpu_ctx.render(p)
+    assert same_bits(gpu_ctx.read_radiance(), img)
+    st2 = gpu_ctx.stats()
+    for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples", "max_stack"):
+        assert st2[k] == st[k], k
 
 
 def test_bvh4_wide_input_gives_same_hits(rt, orc, gpu_ctx):
@@ -138,7 +145,10 @@ def test_tile_sharding_matches_whole_frame(rt, gpu_ctx):
     gpu_ctx.build_bvh()
     w, h = 200, 120
     kw = dict(mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=5)
+    gpu_ctx.render(gpu_ctx.make_params(w, h, simple_kernel=True, **kw))
+    simple = gpu_ctx.read_radiance().copy()
     gpu_ctx.render(gpu_ctx.make_params(w, h, **kw))
+    assert same_bits(gpu_ctx.read_radiance(), simple)
     full = gpu_ctx.read_radiance().copy()
     hip = C.CDLL("libamdhip64.so")
     for count in (2, 3, 8):
