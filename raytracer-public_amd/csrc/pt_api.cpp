@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -57,6 +58,8 @@ struct PtContext {
     DevBuf<uint32_t> d_tiles, d_u32tmp, d_queue;
     DevBuf<float4> d_samples;
     DevBuf<uint2> d_spill;
+    DevBuf<float4> d_cont;
+    DevBuf<unsigned long long> d_wave_times; uint32_t wave_times_n = 0;
     int num_cus = 0;
     DevBuf<unsigned long long> d_stats;
     std::vector<uint32_t> tiles_host; uint32_t tiles_w = 0, tiles_h = 0, tiles_rank = 0, tiles_count = 0;
@@ -84,6 +87,12 @@ int bind(PtContext* ctx) {
     if (!ctx) return fail(nullptr, PT_ERR_INVALID_ARG, "null context");
     PT_HIP(ctx, hipSetDevice(ctx->device));
     return PT_OK;
+}
+
+// development knob: integer override from the environment (defaults are the tuned values)
+uint32_t tune(const char* name, uint32_t dflt) {
+    const char* v = std::getenv(name);
+    return v && *v ? uint32_t(std::strtoul(v, nullptr, 10)) : dflt;
 }
 
 int upload_wide(PtContext* ctx, const uint32_t* bvh4, uint64_t words) {
@@ -127,7 +136,7 @@ int pt_create(int device_ordinal, PtContext** out) {
     e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop);
-    if (e == hipSuccess) e = ctx->d_stats.ensure(8);
+    if (e == hipSuccess) e = ctx->d_stats.ensure(16);
     if (e == hipSuccess) e = ctx->d_queue.ensure(16);
     if (e == hipSuccess) { hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, dev); if (e == hipSuccess) ctx->num_cus = prop.multiProcessorCount; }
     if (e != hipSuccess) { int rc = fail_hip(nullptr, e, "pt_create"); pt_destroy(ctx); return rc; }
@@ -144,7 +153,7 @@ void pt_destroy(PtContext* ctx) {
     ctx->d_morton.release(); ctx->d_triidx.release(); ctx->d_parent.release(); ctx->d_flags.release();
     ctx->d_out.release(); ctx->d_accum.release(); ctx->d_compact.release(); ctx->d_compact_accum.release();
     ctx->d_tiles.release(); ctx->d_u32tmp.release(); ctx->d_stats.release();
-    ctx->d_queue.release(); ctx->d_samples.release(); ctx->d_spill.release();
+    ctx->d_queue.release(); ctx->d_samples.release(); ctx->d_spill.release(); ctx->d_cont.release(); ctx->d_wave_times.release();
     for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -428,7 +437,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         ctx->accum_count = 0;
     }
     if (stats) {
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(unsigned long long), ctx->stream));
         A.stats = ctx->d_stats.ptr;
     }
     ctx->last_stats = stats;
@@ -440,10 +449,16 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         A.num_batches = A.num_tiles * p->spp;
         A.perm_cols = (A.num_batches + 63u) / 64u;
         A.total_items = A.perm_cols * 64u * 64u;
-        A.chunk_items = 256u;
+        A.chunk_items = tune("PT_TUNE_CHUNK", 256u);
+        A.shade_threshold = tune("PT_TUNE_SHADE", PT_SHADE_THRESHOLD); A.fill_threshold = tune("PT_TUNE_FILL", PT_FILL_THRESHOLD);
+        A.flush_threshold = tune("PT_TUNE_FLUSH", PT_FLUSH_THRESHOLD); A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES);
         PT_HIP(ctx, ctx->d_samples.ensure(size_t(A.num_batches) * 64u));
         PT_HIP(ctx, ctx->d_spill.ensure(size_t(grid) * 256u * size_t(64 - PT_SHORT_STACK)));
         A.samples = ctx->d_samples.ptr; A.queue = ctx->d_queue.ptr; A.spill = ctx->d_spill.ptr;
+        A.cont_capacity = grid * 256u;
+        PT_HIP(ctx, ctx->d_cont.ensure(size_t(A.cont_capacity) * 4u * 2u));
+        A.cont_out = ctx->d_cont.ptr;
+        if (stats) { PT_HIP(ctx, ctx->d_wave_times.ensure(size_t(grid) * 4u * 16u)); PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(grid) * 4u * 16u * 8u, ctx->stream)); A.wave_times = ctx->d_wave_times.ptr; ctx->wave_times_n = grid * 4u; }
         // timing ring: events tightly around the dominant kernel; otherwise around the whole pass
         if (!ring) PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
         PT_HIP(ctx, ptk::launch_megakernel(A, stats, grid, ctx->stream, ring ? e0 : nullptr, ring ? e1 : nullptr));
@@ -501,6 +516,22 @@ int pt_get_stats(PtContext* ctx, PtStats* out) {
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out->rays_closest = h[0]; out->rays_shadow = h[1]; out->nodes_examined = h[2]; out->tris_tested = h[3];
     out->stack_drops = h[4]; out->max_stack = h[5]; out->samples = h[6];
+    return PT_OK;
+}
+
+/* diagnostics (not in the public header): raw counter block of the last STATS launch */
+int pt_debug_counters(PtContext* ctx, unsigned long long* dst16) {
+    if (int rc = bind(ctx)) return rc;
+    PT_HIP(ctx, hipMemcpy(dst16, ctx->d_stats.ptr, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+/* diagnostics (not in the public header): per-wave timeline of the last STATS megakernel launch */
+int pt_debug_wave_times(PtContext* ctx, unsigned long long* dst, uint32_t max_waves, uint32_t* n_waves) {
+    if (int rc = bind(ctx)) return rc;
+    const uint32_t n = ctx->wave_times_n < max_waves ? ctx->wave_times_n : max_waves;
+    if (n) PT_HIP(ctx, hipMemcpy(dst, ctx->d_wave_times.ptr, size_t(n) * 128u, hipMemcpyDeviceToHost));
+    if (n_waves) *n_waves = n;
     return PT_OK;
 }
 

@@ -22,8 +22,9 @@ __device__ __forceinline__ float dot3(F3 a, F3 b) { return (a.x * b.x + a.y * b.
 __device__ __forceinline__ F3 cross3(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 __device__ __forceinline__ F3 normalize3(F3 v) { const float inv = 1.0f / sqrtf(dot3(v, v)); return v * inv; }
 // WGSL min/max on non-NaN data (sign of zero never reaches a comparison result)
-__device__ __forceinline__ float wmin(float a, float b) { return (b < a) ? b : a; }
-__device__ __forceinline__ float wmax(float a, float b) { return (b > a) ? b : a; }
+// -> v_min_f32 / v_max_f32 / v_min3_f32 / v_max3_f32
+__device__ __forceinline__ float wmin(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float wmax(float a, float b) { return __builtin_fmaxf(a, b); }
 
 __device__ __forceinline__ float half_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
 __device__ __forceinline__ float half_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
@@ -68,7 +69,7 @@ __device__ __forceinline__ bool slab(const Ray& r, uint32_t w0, uint32_t w1, uin
     const float tmin = wmax(wmax(wmin(t1.x, t2.x), wmin(t1.y, t2.y)), wmin(t1.z, t2.z));
     const float tmax = wmin(wmin(wmax(t1.x, t2.x), wmax(t1.y, t2.y)), wmax(t1.z, t2.z));
     tmin_out = tmin;
-    return (tmax >= wmax(tmin, 0.0f)) && (tmin < best);
+    return (tmax >= wmax(tmin, 0.0f)) & (tmin < best);
 }
 
 // ---- build-defined sampling; integer hash + fixed fmaf polynomials ----

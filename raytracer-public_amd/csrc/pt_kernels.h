@@ -17,6 +17,12 @@
 #ifndef PT_SHADE_THRESHOLD
 #define PT_SHADE_THRESHOLD 16      // shade when this many lanes of a wavefront wait with a finished ray
 #endif
+#ifndef PT_FLUSH_THRESHOLD
+#define PT_FLUSH_THRESHOLD 32      // once the queue is dry, a wavefront with fewer live lanes hands its paths to the next pass
+#endif
+#ifndef PT_MAX_CONT_PASSES
+#define PT_MAX_CONT_PASSES 0       // continuation passes after pass 0 (the last one runs every path to its end)
+#endif
 #ifndef PT_FILL_THRESHOLD
 #define PT_FILL_THRESHOLD 16       // regenerate when this many lanes of a wavefront are without a path
 #endif
@@ -51,8 +57,14 @@ struct RenderArgs {
     float4*   samples;          // per-sample radiance, item = (slot*spp + s)*64 + lane_in_tile
     uint32_t* queue;            // global item cursor
     uint2*    spill;            // deep stack entries: [entry][grid lane]
+    unsigned long long* wave_times;   // STATS diagnostics: 8 words per wave (begin, queue-empty, end ticks @100 MHz, loop counts)
     uint32_t  total_items, chunk_items;   // logical items (64*64*perm_cols) and items per queue claim
     uint32_t  num_batches, perm_cols;     // real (tile,sample) batches; columns of the 64-row batch transpose
+    // continuation records (64 B: o, d, T, rad, key, item, bounce) handed from pass to pass
+    float4*   cont_out; uint32_t* cont_out_count;
+    const float4* cont_in; const uint32_t* cont_in_count;
+    uint32_t  cont_capacity, flush_threshold, cont_passes;
+    uint32_t  shade_threshold, fill_threshold;
 };
 
 hipError_t launch_render(const RenderArgs& args, int kmode, bool stats, hipStream_t stream);

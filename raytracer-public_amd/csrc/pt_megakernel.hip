@@ -41,12 +41,14 @@ struct Lane {
 
 constexpr uint32_t kShadowBit = 1u << 16, kContBit = 1u << 17;
 
-template <bool STATS>
+// CONT = false: pass 0, items are pixel-samples generated from the permuted batch queue.
+// CONT = true : continuation pass, items are path records flushed by the previous pass.
+template <bool STATS, bool CONT>
 __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kernel(const RenderArgs A) {
-    __shared__ uint2 lds_stack[4][kShort][64];
+    __shared__ unsigned long long lds_stack[4][kShort][64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint2* const stk = &lds_stack[wave][0][lane];                       // entry i at stk[i * 64]
-    uint2* const spill = A.spill + ((size_t)blockIdx.x * 256u + threadIdx.x);   // entry j at spill[j * spill_stride]
+    unsigned long long* const stk = &lds_stack[wave][0][lane];          // entry i at stk[i * 64]: (tmin bits << 32) | ref
+    unsigned long long* const spill = (unsigned long long*)A.spill + ((size_t)blockIdx.x * 256u + threadIdx.x);   // entry j at spill[j * spill_stride]
     const size_t spill_stride = (size_t)gridDim.x * 256u;
 
     const F3 base = f3(0.9f, 0.7f, 0.3f);
@@ -54,6 +56,11 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
     const F3 invL = safe_inv(L);
     const bool scene_empty = (A.root_ref == kInvalidRef) || (A.num_tris == 0u) || (A.root_degenerate != 0u);
 
+    unsigned long long t_begin = 0, t_qempty = 0;
+    uint32_t n_iter = 0, n_shade = 0, n_fill = 0, n_iter_q = 0; unsigned long long lanes_sum = 0, lanes_sum_q = 0, leaf_lanes = 0; uint32_t spill_ops = 0, push_ops = 0, push8_ops = 0, push12_ops = 0;
+    if (STATS) t_begin = wall_clock64();
+    const uint32_t total_items = CONT ? min(*A.cont_in_count, A.cont_capacity) : A.total_items;
+    const uint32_t chunk_items = CONT ? 64u : A.chunk_items;
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: this wave's private item range
     bool queue_empty = false;                 // wave-uniform
 
@@ -66,8 +73,9 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
     // ---- helpers as lambdas (all inlined) -------------------------------------------------
     auto push = [&](uint32_t ref, float tmin) {
         if (S.sp < kStackMax) {
-            const uint2 e = make_uint2(ref, __float_as_uint(tmin));
-            if (S.sp < kShort) stk[S.sp * 64] = e; else spill[(size_t)(S.sp - kShort) * spill_stride] = e;
+            const unsigned long long e = ((unsigned long long)__float_as_uint(tmin) << 32) | ref;
+            if (__builtin_expect(S.sp < kShort, 1)) stk[S.sp * 64] = e; else spill[(size_t)(S.sp - kShort) * spill_stride] = e;
+            if (STATS) { if (S.sp >= kShort) ++spill_ops; if (S.sp >= 8) ++push8_ops; if (S.sp >= 12) ++push12_ops; ++push_ops; }
             ++S.sp;
         } else if (STATS) ++c_drops;
     };
@@ -88,7 +96,12 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
         {
             const unsigned long long m_done = __ballot(phase == kPhaseDone);
             const unsigned long long m_trav = __ballot(phase == kPhaseTrav);
-            if (m_done != 0ull && (__popcll(m_done) >= PT_SHADE_THRESHOLD || m_trav == 0ull)) {
+            if (m_done != 0ull && ((uint32_t)__popcll(m_done) >= A.shade_threshold || m_trav == 0ull)) {
+                if (STATS) ++n_shade;
+                // sparse wavefront and nothing left to regenerate from: hand the surviving paths to the
+                // next pass (at a closest-ray boundary) instead of finishing them at low lane utilisation
+                const bool flush_now = queue_empty && (uint32_t)__popcll(m_done | m_trav) < A.flush_threshold;
+                bool do_flush = false;
                 if (phase == kPhaseDone) {
                     const bool hit = S.best_tri != kInvalidRef;
                     const uint32_t bounce = S.bounce & 0xffffu;
@@ -126,6 +139,7 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
                             S.d = S.d_next; S.inv = safe_inv(S.d); S.bounce = bounce + 1u; launch = true;
                         } else finish = true;
                     }
+                    if (launch && flush_now && !(S.bounce & kShadowBit)) { launch = false; do_flush = true; }
                     if (launch) {
                         if (STATS) { if (S.bounce & kShadowBit) ++c_shadow; else ++c_closest; }
                         phase = begin_ray() ? kPhaseTrav : kPhaseDone;   // a root miss is shaded on the next pass
@@ -135,26 +149,53 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
                         phase = kPhaseIdle;
                     }
                 }
+                const unsigned long long m_flush = __ballot(do_flush);
+                if (m_flush != 0ull) {
+                    uint32_t base_idx = 0;
+                    if (lane == (uint32_t)__builtin_ctzll(m_flush)) base_idx = atomicAdd(A.cont_out_count, (uint32_t)__popcll(m_flush));
+                    base_idx = __shfl(base_idx, __builtin_ctzll(m_flush));
+                    if (do_flush) {
+                        const uint32_t idx = base_idx + (uint32_t)__popcll(m_flush & ((1ull << lane) - 1ull));
+                        if (idx < A.cont_capacity) {   // capacity = grid lanes, cannot overflow (<= 64 flushes per wave and pass)
+                            float4* rec = A.cont_out + (size_t)idx * 4;
+                            rec[0] = make_float4(S.o.x, S.o.y, S.o.z, S.d.x);
+                            rec[1] = make_float4(S.d.y, S.d.z, S.T.x, S.T.y);
+                            rec[2] = make_float4(S.T.z, S.rad.x, S.rad.y, S.rad.z);
+                            rec[3] = make_float4(__uint_as_float(S.key), __uint_as_float(S.item), __uint_as_float(S.bounce), 0.0f);
+                        }
+                        phase = kPhaseIdle;
+                    }
+                }
             }
         }
         // ------------------------------------------------------------------ refill IDLE lanes
         {
             const unsigned long long m_idle = __ballot(phase == kPhaseIdle);
             const unsigned long long m_trav = __ballot(phase == kPhaseTrav);
-            if (m_idle != 0ull && !queue_empty && (__popcll(m_idle) >= PT_FILL_THRESHOLD || m_trav == 0ull)) {
+            if (m_idle != 0ull && !queue_empty && ((uint32_t)__popcll(m_idle) >= A.fill_threshold || m_trav == 0ull)) {
                 const uint32_t want = (uint32_t)__popcll(m_idle);
+                if (STATS) ++n_fill;
                 if (chunk_end - chunk_next < want && chunk_next == chunk_end) {
                     // claim a new chunk (one atomic per wave and chunk)
                     uint32_t start = 0;
-                    if (lane == 0) start = atomicAdd(A.queue, A.chunk_items);
+                    if (lane == 0) start = atomicAdd(A.queue, chunk_items);
                     start = __builtin_amdgcn_readfirstlane(start);
-                    if (start >= A.total_items) { queue_empty = true; }
-                    else { chunk_next = start; chunk_end = min(start + A.chunk_items, A.total_items); }
+                    if (start >= total_items) { queue_empty = true; if (STATS) { t_qempty = wall_clock64(); n_iter_q = n_iter; lanes_sum_q = lanes_sum; } }
+                    else { chunk_next = start; chunk_end = min(start + chunk_items, total_items); }
                 }
                 if (!queue_empty) {
                     const uint32_t rank = (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull));
                     const uint32_t avail = chunk_end - chunk_next;
                     if (phase == kPhaseIdle && rank < avail) {
+                        if (CONT) {
+                            const float4* rec = A.cont_in + (size_t)(chunk_next + rank) * 4;
+                            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                            S.o = f3(r0.x, r0.y, r0.z); S.d = f3(r0.w, r1.x, r1.y); S.inv = safe_inv(S.d);
+                            S.T = f3(r1.z, r1.w, r2.x); S.rad = f3(r2.y, r2.z, r2.w);
+                            S.key = __float_as_uint(r3.x); S.item = __float_as_uint(r3.y); S.bounce = __float_as_uint(r3.z);
+                            if (STATS) ++c_closest;
+                            phase = begin_ray() ? kPhaseTrav : kPhaseDone;
+                        } else {
                         // logical item -> batch permutation: 64 consecutive logical items are one
                         // (tile, sample) batch; consecutive logical batches are perm_cols batches apart in
                         // image order, so every claimed chunk holds the frame's average mix of hits and misses
@@ -175,12 +216,10 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
                             S.key = key; S.item = item; S.bounce = 0u;
                             S.T = f3(1.0f, 1.0f, 1.0f); S.rad = f3(0.0f, 0.0f, 0.0f);
                             if (STATS) { ++c_closest; ++c_samples; }
+                            // a camera ray that misses the root box keeps the prefilled sample value
+                            // (0 + 1 * 0.01, renderer.wgsl:410) and the lane stays idle
                             if (begin_ray()) phase = kPhaseTrav;
-                            else {
-                                // camera ray misses the root box: rad = 0 + 1 * 0.01
-                                const F3 rr = S.rad + S.T * kBgPrimary;
-                                A.samples[item] = make_float4(rr.x, rr.y, rr.z, 1.0f);
-                            }
+                        }
                         }
                     }
                     chunk_next += min(want, avail);
@@ -195,6 +234,7 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
             continue;
         }
         // ------------------------------------------------------------------ one traversal step
+        if (STATS) { ++n_iter; lanes_sum += __popcll(m_trav); leaf_lanes += __popcll(__ballot(phase == kPhaseTrav && (S.cur & kLeaf))); }
         if (phase == kPhaseTrav) {
             bool need_pop = false;
             Ray r; r.o = S.o; r.d = S.d; r.inv = S.inv;
@@ -205,23 +245,22 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
                     const float4 a = tp[0], b = tp[1], c = tp[2];
                     if (STATS) ++c_tris;
                     const F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
+                    // branch-free Moller-Trumbore (renderer.wgsl:185-205): same operations and comparisons,
+                    // rejections combined at the end, so the 48 B record is fetched in one go
                     const F3 pv = cross3(r.d, e2);
                     const float det = dot3(e1, pv);
-                    if (!(fabsf(det) < kTriEps)) {
-                        const float inv_det = 1.0f / det;
-                        const F3 sv = r.o - v0;
-                        const float u = inv_det * dot3(sv, pv);
-                        if (!(u < 0.0f || u > 1.0f)) {
-                            const F3 q = cross3(sv, e1);
-                            const float v = inv_det * dot3(r.d, q);
-                            if (!(v < 0.0f || (u + v) > 1.0f)) {
-                                const float t = inv_det * dot3(e2, q);
-                                if (t > kTriEps && t < S.best_t) {
-                                    S.best_t = t; S.best_tri = ti;
-                                    if (S.bounce & kShadowBit) phase = kPhaseDone;   // any-hit: first accepted hit ends the ray
-                                }
-                            }
-                        }
+                    const bool ok_det = !(fabsf(det) < kTriEps);
+                    const float inv_det = 1.0f / det;
+                    const F3 sv = r.o - v0;
+                    const float u = inv_det * dot3(sv, pv);
+                    const bool ok_u = !((u < 0.0f) | (u > 1.0f));
+                    const F3 q = cross3(sv, e1);
+                    const float v = inv_det * dot3(r.d, q);
+                    const bool ok_v = !((v < 0.0f) | ((u + v) > 1.0f));
+                    const float t = inv_det * dot3(e2, q);
+                    if (ok_det & ok_u & ok_v & (t > kTriEps) & (t < S.best_t)) {
+                        S.best_t = t; S.best_tri = ti;
+                        if (S.bounce & kShadowBit) phase = kPhaseDone;   // any-hit: first accepted hit ends the ray
                     }
                 }
                 need_pop = true;
@@ -229,21 +268,33 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
                 const uint4* np = A.nodes + (size_t)S.cur * 4;
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                 float t0, t1, t2, t3;
-                const bool h0 = (n3.x != kInvalidRef) && slab(r, n0.x, n0.y, n0.z, S.best_t, t0);
-                const bool h1 = (n3.y != kInvalidRef) && slab(r, n0.w, n1.x, n1.y, S.best_t, t1);
-                const bool h2 = (n3.z != kInvalidRef) && slab(r, n1.z, n1.w, n2.x, S.best_t, t2);
-                const bool h3 = (n3.w != kInvalidRef) && slab(r, n2.y, n2.z, n2.w, S.best_t, t3);
+                // all four slab tests are evaluated unconditionally (empty slots hold zero boxes and are
+                // masked by their ref): one 64 B fetch, no per-child branches or dependent waits
+                const bool s0 = slab(r, n0.x, n0.y, n0.z, S.best_t, t0);
+                const bool s1 = slab(r, n0.w, n1.x, n1.y, S.best_t, t1);
+                const bool s2 = slab(r, n1.z, n1.w, n2.x, S.best_t, t2);
+                const bool s3 = slab(r, n2.y, n2.z, n2.w, S.best_t, t3);
+                const bool h0 = s0 & (n3.x != kInvalidRef), h1 = s1 & (n3.y != kInvalidRef);
+                const bool h2 = s2 & (n3.z != kInvalidRef), h3 = s3 & (n3.w != kInvalidRef);
                 if (STATS) c_nodes += (n3.x != kInvalidRef) + (n3.y != kInvalidRef) + (n3.z != kInvalidRef) + (n3.w != kInvalidRef);
-                int nslot = -1, fslot = -1; float tn = kInfT, tf = 0.0f; uint32_t rn = kInvalidRef, rf = kInvalidRef;
-                if (h0) { nslot = 0; tn = t0; rn = n3.x; fslot = 0; tf = t0; rf = n3.x; }
-                if (h1) { if (nslot < 0 || t1 < tn) { nslot = 1; tn = t1; rn = n3.y; } if (fslot < 0) { fslot = 1; tf = t1; rf = n3.y; } }
-                if (h2) { if (nslot < 0 || t2 < tn) { nslot = 2; tn = t2; rn = n3.z; } if (fslot < 0) { fslot = 2; tf = t2; rf = n3.z; } }
-                if (h3) { if (nslot < 0 || t3 < tn) { nslot = 3; tn = t3; rn = n3.w; } if (fslot < 0) { fslot = 3; tf = t3; rf = n3.w; } }
-                if (nslot < 0) need_pop = true;
+                // Branch-free form of renderer.wgsl:314-342 for one lane.  Hit children keep slot order;
+                // the nearest (first minimum of tmin) is entered next and trades places with the first
+                // hit, so the stacked entry for slot s is the first hit's when s is the nearest slot, the
+                // slot's own child otherwise -- and a slot is stacked iff it is hit and is not the first hit.
+                const float kBig = 3.0e38f;
+                const float e0 = h0 ? t0 : kBig, e1 = h1 ? t1 : kBig, e2 = h2 ? t2 : kBig, e3 = h3 ? t3 : kBig;
+                const float tn = wmin(wmin(e0, e1), wmin(e2, e3));
+                const bool any = h0 | h1 | h2 | h3;
+                const int nslot = (h0 && e0 == tn) ? 0 : (h1 && e1 == tn) ? 1 : (h2 && e2 == tn) ? 2 : 3;
+                const uint32_t rn = nslot == 0 ? n3.x : nslot == 1 ? n3.y : nslot == 2 ? n3.z : n3.w;
+                const uint32_t rf = h0 ? n3.x : h1 ? n3.y : h2 ? n3.z : n3.w;      // first hit
+                const float tf = h0 ? t0 : h1 ? t1 : h2 ? t2 : t3;
+                if (!any) need_pop = true;
                 else {
-                    if (h3) { if (nslot == 3) { if (fslot != 3) push(rf, tf); } else if (fslot != 3) push(n3.w, t3); }
-                    if (h2) { if (nslot == 2) { if (fslot != 2) push(rf, tf); } else if (fslot != 2) push(n3.z, t2); }
-                    if (h1) { if (nslot == 1) { if (fslot != 1) push(rf, tf); } else if (fslot != 1) push(n3.y, t1); }
+                    const bool p3 = h3 & (h0 | h1 | h2), p2 = h2 & (h0 | h1), p1 = h1 & h0;
+                    if (p3) push(nslot == 3 ? rf : n3.w, nslot == 3 ? tf : t3);
+                    if (p2) push(nslot == 2 ? rf : n3.z, nslot == 2 ? tf : t2);
+                    if (p1) push(nslot == 1 ? rf : n3.y, nslot == 1 ? tf : t1);
                     if (STATS) { if ((uint32_t)(S.sp + 1) > c_maxstack) c_maxstack = (uint32_t)(S.sp + 1); }
                     if (S.sp < kStackMax) S.cur = rn;
                     else { need_pop = true; if (STATS) ++c_drops; }
@@ -253,14 +304,21 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
                 bool found = false;
                 while (S.sp > 0) {
                     --S.sp;
-                    const uint2 e = (S.sp < kShort) ? stk[S.sp * 64] : spill[(size_t)(S.sp - kShort) * spill_stride];
-                    if (__uint_as_float(e.y) < S.best_t) { S.cur = e.x; found = true; break; }
+                    const unsigned long long e = __builtin_expect(S.sp < kShort, 1) ? stk[S.sp * 64] : spill[(size_t)(S.sp - kShort) * spill_stride];
+                    if (__uint_as_float((uint32_t)(e >> 32)) < S.best_t) { S.cur = (uint32_t)e; found = true; break; }
                 }
                 if (!found) phase = kPhaseDone;
             }
         }
     }
     if (STATS) {
+        if (!CONT && A.wave_times && lane == 0) {
+            unsigned long long* w = A.wave_times + ((size_t)blockIdx.x * 4u + wave) * 16u;
+            w[0] = t_begin; w[1] = t_qempty; w[2] = wall_clock64(); w[3] = n_iter; w[4] = n_shade; w[5] = n_fill;
+            w[6] = n_iter_q; w[7] = lanes_sum; w[8] = lanes_sum_q; w[9] = leaf_lanes;
+        }
+        atomicAdd(&A.stats[8], (unsigned long long)push_ops); atomicAdd(&A.stats[9], (unsigned long long)push8_ops);
+        atomicAdd(&A.stats[10], (unsigned long long)push12_ops); atomicAdd(&A.stats[11], (unsigned long long)spill_ops);
         atomicAdd(&A.stats[0], (unsigned long long)c_closest);
         atomicAdd(&A.stats[1], (unsigned long long)c_shadow);
         atomicAdd(&A.stats[2], (unsigned long long)c_nodes);
@@ -297,20 +355,49 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
     A.out[out_index] = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, 1.0f);
 }
 
-hipError_t launch_megakernel(const RenderArgs& A, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1) {
-    hipError_t e = hipMemsetAsync(A.queue, 0, sizeof(uint32_t), stream);
+// every sample starts as the camera-ray miss value 0 + 1 * 0.01 (renderer.wgsl:410)
+__global__ __launch_bounds__(256) void prefill_samples_kernel(float4* __restrict__ samples, uint32_t n) {
+    const float v = 0.0f + 1.0f * kBgPrimary;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        samples[i] = make_float4(v, v, v, 1.0f);
+}
+
+hipError_t launch_megakernel(const RenderArgs& A0, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1) {
+    RenderArgs A = A0;
+    // control block: [0] item cursor pass 0, [1..] cursors of the continuation passes, [8], [9] record counts (ping-pong)
+    hipError_t e = hipMemsetAsync(A.queue, 0, 16 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    if (A.total_items != 0u) {
-        if (k0) { e = hipEventRecord(k0, stream); if (e != hipSuccess) return e; }
-        if (stats) hipLaunchKernelGGL((trace_paths_kernel<true>), dim3(grid_blocks), dim3(256), 0, stream, A);
-        else       hipLaunchKernelGGL((trace_paths_kernel<false>), dim3(grid_blocks), dim3(256), 0, stream, A);
+    if (A.total_items == 0u) return hipSuccess;
+    const uint32_t n_samples = A.num_batches * 64u;
+    hipLaunchKernelGGL(prefill_samples_kernel, dim3(2048), dim3(256), 0, stream, A.samples, n_samples);
+    e = hipGetLastError(); if (e != hipSuccess) return e;
+    uint32_t* const ctrl = A0.queue;
+    float4* const rec_a = A0.cont_out; float4* const rec_b = A0.cont_out + (size_t)A0.cont_capacity * 4;
+    const uint32_t passes = A.max_bounces < A0.cont_passes ? A.max_bounces : A0.cont_passes;
+    // pass 0
+    A.queue = ctrl; A.cont_out = rec_a; A.cont_out_count = ctrl + 8;
+    A.flush_threshold = passes > 0 ? A0.flush_threshold : 0u;
+    if (k0) { e = hipEventRecord(k0, stream); if (e != hipSuccess) return e; }
+    if (stats) hipLaunchKernelGGL((trace_paths_kernel<true, false>), dim3(grid_blocks), dim3(256), 0, stream, A);
+    else       hipLaunchKernelGGL((trace_paths_kernel<false, false>), dim3(grid_blocks), dim3(256), 0, stream, A);
+    e = hipGetLastError(); if (e != hipSuccess) return e;
+    // continuation passes: each record advances by at least one closest ray per pass; the last pass never flushes
+    for (uint32_t pass = 1; pass <= passes; ++pass) {
+        const bool odd = (pass & 1u) != 0u;
+        A.queue = ctrl + pass;
+        A.cont_in = odd ? rec_a : rec_b; A.cont_in_count = ctrl + (odd ? 8 : 9);
+        A.cont_out = odd ? rec_b : rec_a; A.cont_out_count = ctrl + (odd ? 9 : 8);
+        A.flush_threshold = (pass < passes) ? (A0.flush_threshold >> pass) : 0u;
+        if (pass >= 2) { e = hipMemsetAsync(A.cont_out_count, 0, sizeof(uint32_t), stream); if (e != hipSuccess) return e; }
+        const uint32_t g = grid_blocks;
+        if (stats) hipLaunchKernelGGL((trace_paths_kernel<true, true>), dim3(g), dim3(256), 0, stream, A);
+        else       hipLaunchKernelGGL((trace_paths_kernel<false, true>), dim3(g), dim3(256), 0, stream, A);
         e = hipGetLastError(); if (e != hipSuccess) return e;
-        if (k1) { e = hipEventRecord(k1, stream); if (e != hipSuccess) return e; }
-        const uint32_t n = A.num_tiles * 64u;
-        hipLaunchKernelGGL(resolve_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, A);
-        e = hipGetLastError();
     }
-    return e;
+    if (k1) { e = hipEventRecord(k1, stream); if (e != hipSuccess) return e; }   // k0..k1 = all trace_paths passes
+    const uint32_t n = A.num_tiles * 64u;
+    hipLaunchKernelGGL(resolve_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, A);
+    return hipGetLastError();
 }
 
 int megakernel_blocks_per_cu() { return PT_MEGA_WAVES_PER_SIMD; }

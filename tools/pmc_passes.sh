@@ -18,7 +18,7 @@ res = collections.OrderedDict()
 for f in sorted(glob.glob("$OUT/pass*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        if "render_rays" not in k: continue
+        if "render_rays" not in k and "trace_paths" not in k: continue
         res.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 summary = {k: sum(v) / len(v) for k, v in res.items()}
 json.dump(summary, open("$OUT/pmc_summary.json", "w"), indent=1)

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of the megakernel (STATS launch): when did each wave see the queue empty,
+when did it exit, how many loop iterations / shade passes / refills did it run."""
+import ctypes as C, importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+rt = importlib.import_module("raytracer-public_amd")
+tris = rt.procedural_scene(0, 871414)
+ctx = rt.Context(0); ctx.set_triangles(tris); ctx.build_bvh()
+p = ctx.make_params(1920, 1080, mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, stats=True)
+ctx.render(p); ctx.render(p)
+print("ms (stats build):", ctx.last_render_ms())
+buf = np.zeros((8192, 16), np.uint64); n = C.c_uint32()
+rt.lib.pt_debug_wave_times(ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_uint32(8192), C.byref(n))
+w = buf[: n.value].astype(np.float64)
+t0 = w[:, 0].min()
+beg, qe, end = (w[:, 0] - t0) / 100.0, (w[:, 1] - t0) / 100.0, (w[:, 2] - t0) / 100.0   # microseconds
+print("waves", n.value)
+for name, v in (("begin", beg), ("queue-empty", qe), ("end", end)):
+    print("%-12s us: min %.0f  p10 %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % ((name,) + tuple(np.percentile(v, [0, 10, 50, 90, 99, 100]))))
+print("iterations per wave: p50 %d max %d ; shade passes p50 %d ; refills p50 %d" % (np.median(w[:, 3]), w[:, 3].max(), np.median(w[:, 4]), np.median(w[:, 5])))
+print("iter time us (p50):", np.median((end - beg) / np.maximum(w[:, 3], 1)))
+live = w[:, 1] > 0
+pre_it, post_it = w[live, 6], w[live, 3] - w[live, 6]
+pre_t, post_t = (qe[live] - beg[live]), (end[live] - qe[live])
+print("pre-exhaustion : iters p50 %d, us/iter p50 %.2f, lane util %.1f%%" % (np.median(pre_it), np.median(pre_t / np.maximum(pre_it, 1)), 100 * w[live, 8].sum() / (64 * pre_it.sum())))
+print("post-exhaustion: iters p50 %d, us/iter p50 %.2f, lane util %.1f%%" % (np.median(post_it), np.median(post_t / np.maximum(post_it, 1)), 100 * (w[live, 7] - w[live, 8]).sum() / (64 * np.maximum(post_it.sum(), 1))))
+print("leaf-lane share of traversing lanes: %.1f%%" % (100 * w[:, 9].sum() / w[:, 7].sum()))
+print("total wave-iterations %.3fM, lane-steps %.1fM" % (w[:, 3].sum() / 1e6, w[:, 7].sum() / 1e6))
+st = ctx.stats(); print(st)
+dbg = np.zeros(16, np.uint64); rt.lib.pt_debug_counters(ctx.h, dbg.ctypes.data_as(C.c_void_p))
+print('pushes %d, at depth>=8 %.2f%%, >=12 %.2f%%, spilled(>=kShort) %.3f%%' % (dbg[8], 100.0 * dbg[9] / dbg[8], 100.0 * dbg[10] / dbg[8], 100.0 * dbg[11] / dbg[8]))
