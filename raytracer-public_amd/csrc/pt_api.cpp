@@ -100,7 +100,7 @@ int upload_wide(PtContext* ctx, const uint32_t* bvh4, uint64_t words) {
     if (!pt::build_wide_bvh(bvh4, words, w, err)) return fail(ctx, PT_ERR_BAD_BVH, err);
     PT_HIP(ctx, ctx->d_bvh4.ensure(words));
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh4.ptr, bvh4, words * 4, hipMemcpyHostToDevice, ctx->stream));
-    PT_HIP(ctx, ctx->d_wide.ensure(w.nodes.size() * 4));
+    PT_HIP(ctx, ctx->d_wide.ensure(w.nodes.size() * 4 + 4));
     if (!w.nodes.empty())
         PT_HIP(ctx, hipMemcpyAsync(ctx->d_wide.ptr, w.nodes.data(), w.nodes.size() * sizeof(pt::WideNode), hipMemcpyHostToDevice, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die at return
@@ -248,7 +248,7 @@ int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris) {
     if (num_tris && !tris) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_triangles: null triangles");
     if (num_tris >= 0x7fffffffu) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_triangles: too many triangles for the 31-bit leaf index");
     PT_HIP(ctx, ctx->d_tris9.ensure(size_t(num_tris) * 9));
-    PT_HIP(ctx, ctx->d_trirec.ensure(size_t(num_tris) * 3));
+    PT_HIP(ctx, ctx->d_trirec.ensure(size_t(num_tris) * 3 + 4));   // +64 B: the megakernel's unified 64 B fetch over-reads the last record
     std::vector<pt::TriRecord> rec(num_tris);
     pt::build_tri_records(tris, num_tris, rec.data());
     if (num_tris) {

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
     const bool scene_empty = (A.root_ref == kInvalidRef) || (A.num_tris == 0u) || (A.root_degenerate != 0u);
 
     unsigned long long t_begin = 0, t_qempty = 0;
-    uint32_t n_iter = 0, n_shade = 0, n_fill = 0, n_iter_q = 0; unsigned long long lanes_sum = 0, lanes_sum_q = 0, leaf_lanes = 0; uint32_t spill_ops = 0, push_ops = 0, push8_ops = 0, push12_ops = 0;
+    uint32_t n_iter = 0, n_shade = 0, n_fill = 0, n_iter_q = 0; unsigned long long cy_shade = 0, cy_fill = 0, cy_step = 0, cy_step_q = 0, cy_mark = 0; unsigned long long lanes_sum = 0, lanes_sum_q = 0, leaf_lanes = 0; uint32_t spill_ops = 0, push_ops = 0, push8_ops = 0, push12_ops = 0;
     if (STATS) t_begin = wall_clock64();
     const uint32_t total_items = CONT ? min(*A.cont_in_count, A.cont_capacity) : A.total_items;
     const uint32_t chunk_items = CONT ? 64u : A.chunk_items;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
             const unsigned long long m_done = __ballot(phase == kPhaseDone);
             const unsigned long long m_trav = __ballot(phase == kPhaseTrav);
             if (m_done != 0ull && ((uint32_t)__popcll(m_done) >= A.shade_threshold || m_trav == 0ull)) {
-                if (STATS) ++n_shade;
+                if (STATS) { ++n_shade; cy_mark = __builtin_amdgcn_s_memtime(); }
                 // sparse wavefront and nothing left to regenerate from: hand the surviving paths to the
                 // next pass (at a closest-ray boundary) instead of finishing them at low lane utilisation
                 const bool flush_now = queue_empty && (uint32_t)__popcll(m_done | m_trav) < A.flush_threshold;
@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
                         phase = kPhaseIdle;
                     }
                 }
+                if (STATS) cy_shade += __builtin_amdgcn_s_memtime() - cy_mark;
             }
         }
         // ------------------------------------------------------------------ refill IDLE lanes
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
             const unsigned long long m_trav = __ballot(phase == kPhaseTrav);
             if (m_idle != 0ull && !queue_empty && ((uint32_t)__popcll(m_idle) >= A.fill_threshold || m_trav == 0ull)) {
                 const uint32_t want = (uint32_t)__popcll(m_idle);
-                if (STATS) ++n_fill;
+                if (STATS) { ++n_fill; cy_mark = __builtin_amdgcn_s_memtime(); }
                 if (chunk_end - chunk_next < want && chunk_next == chunk_end) {
                     // claim a new chunk (one atomic per wave and chunk)
                     uint32_t start = 0;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
                     }
                     chunk_next += min(want, avail);
                 }
+                if (STATS) cy_fill += __builtin_amdgcn_s_memtime() - cy_mark;
             }
         }
         // ------------------------------------------------------------------ exit / idle-spin
@@ -234,15 +236,24 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
             continue;
         }
         // ------------------------------------------------------------------ one traversal step
-        if (STATS) { ++n_iter; lanes_sum += __popcll(m_trav); leaf_lanes += __popcll(__ballot(phase == kPhaseTrav && (S.cur & kLeaf))); }
+        if (STATS) { cy_mark = __builtin_amdgcn_s_memtime(); ++n_iter; lanes_sum += __popcll(m_trav); leaf_lanes += __popcll(__ballot(phase == kPhaseTrav && (S.cur & kLeaf))); }
         if (phase == kPhaseTrav) {
             bool need_pop = false;
             Ray r; r.o = S.o; r.d = S.d; r.inv = S.inv;
-            if (S.cur & kLeaf) {
-                const uint32_t ti = S.cur & 0x7fffffffu;
-                if (ti < A.num_tris) {
-                    const float4* tp = A.tris + (size_t)ti * 3;
-                    const float4 a = tp[0], b = tp[1], c = tp[2];
+            // Unified fetch: a lane is either at an internal node (64 B record) or at a leaf (48 B
+            // triangle record).  Both kinds are fetched by the same four dwordx4 loads BEFORE the
+            // node/leaf branch, so a wavefront with mixed lanes pays one memory latency per step, not
+            // two.  (A leaf lane over-reads 16 B into the next record; the buffers are padded.)
+            const bool at_leaf = (S.cur & kLeaf) != 0u;
+            const uint32_t ti = S.cur & 0x7fffffffu;
+            const bool tri_ok = ti < A.num_tris;
+            const uint4* rec = at_leaf ? (const uint4*)(A.tris + (size_t)(tri_ok ? ti : 0u) * 3) : (A.nodes + (size_t)S.cur * 4);
+            const uint4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+            if (at_leaf) {
+                if (tri_ok) {
+                    const float4 a = make_float4(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z), __uint_as_float(n0.w));
+                    const float4 b = make_float4(__uint_as_float(n1.x), __uint_as_float(n1.y), __uint_as_float(n1.z), __uint_as_float(n1.w));
+                    const float4 c = make_float4(__uint_as_float(n2.x), __uint_as_float(n2.y), __uint_as_float(n2.z), __uint_as_float(n2.w));
                     if (STATS) ++c_tris;
                     const F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
                     // branch-free Moller-Trumbore (renderer.wgsl:185-205): same operations and comparisons,
@@ -265,8 +276,6 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
                 }
                 need_pop = true;
             } else {
-                const uint4* np = A.nodes + (size_t)S.cur * 4;
-                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                 float t0, t1, t2, t3;
                 // all four slab tests are evaluated unconditionally (empty slots hold zero boxes and are
                 // masked by their ref): one 64 B fetch, no per-child branches or dependent waits
@@ -285,16 +294,33 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
                 const float e0 = h0 ? t0 : kBig, e1 = h1 ? t1 : kBig, e2 = h2 ? t2 : kBig, e3 = h3 ? t3 : kBig;
                 const float tn = wmin(wmin(e0, e1), wmin(e2, e3));
                 const bool any = h0 | h1 | h2 | h3;
-                const int nslot = (h0 && e0 == tn) ? 0 : (h1 && e1 == tn) ? 1 : (h2 && e2 == tn) ? 2 : 3;
-                const uint32_t rn = nslot == 0 ? n3.x : nslot == 1 ? n3.y : nslot == 2 ? n3.z : n3.w;
+                // nearest slot = first slot (in slot order) whose tmin equals the minimum
+                const bool m0 = h0 & (e0 == tn), m1 = h1 & (e1 == tn) & !m0, m2 = h2 & (e2 == tn) & !(m0 | m1);
+                const bool m3 = !(m0 | m1 | m2);
+                const uint32_t rn = m0 ? n3.x : m1 ? n3.y : m2 ? n3.z : n3.w;
                 const uint32_t rf = h0 ? n3.x : h1 ? n3.y : h2 ? n3.z : n3.w;      // first hit
                 const float tf = h0 ? t0 : h1 ? t1 : h2 ? t2 : t3;
                 if (!any) need_pop = true;
                 else {
                     const bool p3 = h3 & (h0 | h1 | h2), p2 = h2 & (h0 | h1), p1 = h1 & h0;
-                    if (p3) push(nslot == 3 ? rf : n3.w, nslot == 3 ? tf : t3);
-                    if (p2) push(nslot == 2 ? rf : n3.z, nslot == 2 ? tf : t2);
-                    if (p1) push(nslot == 1 ? rf : n3.y, nslot == 1 ? tf : t1);
+                    const unsigned long long en = ((unsigned long long)__float_as_uint(tf) << 32) | rf;
+                    const unsigned long long w3 = m3 ? en : (((unsigned long long)__float_as_uint(t3) << 32) | n3.w);
+                    const unsigned long long w2 = m2 ? en : (((unsigned long long)__float_as_uint(t2) << 32) | n3.z);
+                    const unsigned long long w1 = m1 ? en : (((unsigned long long)__float_as_uint(t1) << 32) | n3.y);
+                    if (__builtin_expect(S.sp + 3 <= kShort, 1)) {
+                        // fast path: three unconditional LDS stores far -> near; an entry that is not
+                        // stacked is simply overwritten by the next one (the slot index does not advance)
+                        int sp = S.sp;
+                        stk[sp * 64] = w3; sp += p3 ? 1 : 0;
+                        stk[sp * 64] = w2; sp += p2 ? 1 : 0;
+                        stk[sp * 64] = w1; sp += p1 ? 1 : 0;
+                        if (STATS) { const int k = sp - S.sp; push_ops += k; for (int j = S.sp; j < sp; ++j) { if (j >= 8) ++push8_ops; if (j >= 12) ++push12_ops; } }
+                        S.sp = sp;
+                    } else {
+                        if (p3) push((uint32_t)w3, __uint_as_float((uint32_t)(w3 >> 32)));
+                        if (p2) push((uint32_t)w2, __uint_as_float((uint32_t)(w2 >> 32)));
+                        if (p1) push((uint32_t)w1, __uint_as_float((uint32_t)(w1 >> 32)));
+                    }
                     if (STATS) { if ((uint32_t)(S.sp + 1) > c_maxstack) c_maxstack = (uint32_t)(S.sp + 1); }
                     if (S.sp < kStackMax) S.cur = rn;
                     else { need_pop = true; if (STATS) ++c_drops; }
@@ -304,18 +330,22 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
                 bool found = false;
                 while (S.sp > 0) {
                     --S.sp;
-                    const unsigned long long e = __builtin_expect(S.sp < kShort, 1) ? stk[S.sp * 64] : spill[(size_t)(S.sp - kShort) * spill_stride];
+                    // the LDS slot is read unconditionally (index clamped); deep entries override it from the spill area
+                    unsigned long long e = stk[(S.sp < kShort ? S.sp : kShort - 1) * 64];
+                    if (__builtin_expect(S.sp >= kShort, 0)) e = *(volatile unsigned long long*)&spill[(size_t)(S.sp - kShort) * spill_stride];   // volatile: keeps the rare global read out of the LDS fast path
                     if (__uint_as_float((uint32_t)(e >> 32)) < S.best_t) { S.cur = (uint32_t)e; found = true; break; }
                 }
                 if (!found) phase = kPhaseDone;
             }
         }
+        if (STATS) { const unsigned long long dt = __builtin_amdgcn_s_memtime() - cy_mark; cy_step += dt; if (!queue_empty) cy_step_q += dt; }
     }
     if (STATS) {
         if (!CONT && A.wave_times && lane == 0) {
             unsigned long long* w = A.wave_times + ((size_t)blockIdx.x * 4u + wave) * 16u;
             w[0] = t_begin; w[1] = t_qempty; w[2] = wall_clock64(); w[3] = n_iter; w[4] = n_shade; w[5] = n_fill;
             w[6] = n_iter_q; w[7] = lanes_sum; w[8] = lanes_sum_q; w[9] = leaf_lanes;
+            w[10] = cy_shade; w[11] = cy_fill; w[12] = cy_step; w[13] = cy_step_q;
         }
         atomicAdd(&A.stats[8], (unsigned long long)push_ops); atomicAdd(&A.stats[9], (unsigned long long)push8_ops);
         atomicAdd(&A.stats[10], (unsigned long long)push12_ops); atomicAdd(&A.stats[11], (unsigned long long)spill_ops);

@@ -27,6 +27,9 @@ print("pre-exhaustion : iters p50 %d, us/iter p50 %.2f, lane util %.1f%%" % (np.
 print("post-exhaustion: iters p50 %d, us/iter p50 %.2f, lane util %.1f%%" % (np.median(post_it), np.median(post_t / np.maximum(post_it, 1)), 100 * (w[live, 7] - w[live, 8]).sum() / (64 * np.maximum(post_it.sum(), 1))))
 print("leaf-lane share of traversing lanes: %.1f%%" % (100 * w[:, 9].sum() / w[:, 7].sum()))
 print("total wave-iterations %.3fM, lane-steps %.1fM" % (w[:, 3].sum() / 1e6, w[:, 7].sum() / 1e6))
+tot = (w[:, 2] - w[:, 0]).sum() * 24.0   # 100 MHz ticks -> ~2.4 GHz cycles
+print('cycle shares of wave lifetime (s_memtime): shade %.1f%%, refill %.1f%%, traversal step %.1f%% (pre-exhaustion %.1f%%)' % tuple(100 * w[:, k].sum() / tot for k in (10, 11, 12, 13)))
+print('cycles per shade pass %.0f, per refill %.0f, per step pre %.0f, post %.0f' % (w[:, 10].sum() / w[:, 4].sum(), w[:, 11].sum() / w[:, 5].sum(), w[live, 13].sum() / pre_it.sum(), (w[live, 12] - w[live, 13]).sum() / post_it.sum()))
 st = ctx.stats(); print(st)
 dbg = np.zeros(16, np.uint64); rt.lib.pt_debug_counters(ctx.h, dbg.ctypes.data_as(C.c_void_p))
 print('pushes %d, at depth>=8 %.2f%%, >=12 %.2f%%, spilled(>=kShort) %.3f%%' % (dbg[8], 100.0 * dbg[9] / dbg[8], 100.0 * dbg[10] / dbg[8], 100.0 * dbg[11] / dbg[8]))
