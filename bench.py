@@ -129,39 +129,39 @@ def main():
         def wait(self):
             pass
 
-    def step(i, p):
-        with torch.cuda.stream(stream):
-            if not sharded:
-                ctx.render(p)
-                return
-            slot = i & 1
-            ctx.set_compact_buffer(compact[slot].data_ptr(), stride)
+    def step(i, p):                  # called with `stream` current
+        if not sharded:
             ctx.render(p)
-            if host_stage:
-                work = _HostWork(compact[slot], slot)
-            else:
-                glist = [gathered[slot][r] for r in range(world)] if rank == 0 else None
-                work = dist.gather(compact[slot], glist, dst=0, async_op=True)
-            finish(pending[0])           # gather(i-1) has had the whole render(i) to complete
-            pending[0] = (work, slot)
+            return
+        slot = i & 1
+        ctx.set_compact_buffer(compact[slot].data_ptr(), stride)
+        ctx.render(p)
+        if host_stage:
+            work = _HostWork(compact[slot], slot)
+        else:
+            glist = [gathered[slot][r] for r in range(world)] if rank == 0 else None
+            work = dist.gather(compact[slot], glist, dst=0, async_op=True)
+        finish(pending[0])               # gather(i-1) has had the whole render(i) to complete
+        pending[0] = (work, slot)
 
     def drain():
-        with torch.cuda.stream(stream):
-            finish(pending[0])
-            pending[0] = None
+        finish(pending[0])
+        pending[0] = None
 
     p = params()
-    for i in range(args.warmup):
-        step(i, p)
-    drain()
+    with torch.cuda.stream(stream):
+        for i in range(args.warmup):
+            step(i, p)
+        drain()
     if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     ctx.timing_begin(args.steps)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, p)
-    drain()
+    with torch.cuda.stream(stream):
+        for i in range(args.steps):
+            step(i, p)
+        drain()
     torch.cuda.synchronize()
     if sharded:
         dist.barrier()
@@ -197,7 +197,9 @@ def main():
                        "sharding": ("interleaved 8x8 tiles over %d GPUs, RCCL gather to rank 0" % world) if sharded else "single GPU, whole frame"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "render_rays_kernel<PATH>", "kernel_avg_ms": round(k_avg_ms, 4),
+                         "kernel": "trace_paths_kernel (persistent megakernel)", "kernel_avg_ms": round(k_avg_ms, 4),
+                         "note": "per-launch duration by hipEvents on the launch stream; up to %d frames' trace kernels overlap on side streams, so a launch's duration exceeds ms_per_step" % int(os.environ.get("PT_TUNE_SLOTS", "6")),
+                         "achieved_from_throughput": round(my_bytes * args.steps / elapsed / 1e9, 2),
                          "algorithmic_bytes_per_launch": my_bytes,
                          "counters": {k: my_stats[k] for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples")}},
         }

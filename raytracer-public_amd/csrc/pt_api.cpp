@@ -55,10 +55,16 @@ struct PtContext {
 
     // frame
     DevBuf<float4> d_out, d_accum, d_compact, d_compact_accum;
-    DevBuf<uint32_t> d_tiles, d_u32tmp, d_queue;
-    DevBuf<float4> d_samples;
-    DevBuf<uint2> d_spill;
-    DevBuf<float4> d_cont;
+    DevBuf<uint32_t> d_tiles, d_u32tmp;
+    // Frame slots: the trace phase of consecutive pt_render calls runs on alternating side streams
+    // (own sample / control / scratch buffers each), so the sparse tail of one frame overlaps the
+    // dense start of the next; the resolve passes stay in call order on the main stream.
+    struct FrameSlot {
+        hipStream_t side = nullptr; hipEvent_t resolved = nullptr, done = nullptr; bool used = false;
+        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<float4> cont;
+    };
+    static constexpr int kMaxSlots = 8;
+    FrameSlot slots[kMaxSlots]; int num_slots = 0; uint32_t next_slot = 0;
     DevBuf<unsigned long long> d_wave_times; uint32_t wave_times_n = 0;
     int num_cus = 0;
     DevBuf<unsigned long long> d_stats;
@@ -137,7 +143,6 @@ int pt_create(int device_ordinal, PtContext** out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop);
     if (e == hipSuccess) e = ctx->d_stats.ensure(16);
-    if (e == hipSuccess) e = ctx->d_queue.ensure(16);
     if (e == hipSuccess) { hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, dev); if (e == hipSuccess) ctx->num_cus = prop.multiProcessorCount; }
     if (e != hipSuccess) { int rc = fail_hip(nullptr, e, "pt_create"); pt_destroy(ctx); return rc; }
     ctx->stream = ctx->own_stream;
@@ -153,7 +158,13 @@ void pt_destroy(PtContext* ctx) {
     ctx->d_morton.release(); ctx->d_triidx.release(); ctx->d_parent.release(); ctx->d_flags.release();
     ctx->d_out.release(); ctx->d_accum.release(); ctx->d_compact.release(); ctx->d_compact_accum.release();
     ctx->d_tiles.release(); ctx->d_u32tmp.release(); ctx->d_stats.release();
-    ctx->d_queue.release(); ctx->d_samples.release(); ctx->d_spill.release(); ctx->d_cont.release(); ctx->d_wave_times.release();
+    ctx->d_wave_times.release();
+    for (auto& sl : ctx->slots) {
+        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.cont.release();
+        if (sl.resolved) (void)hipEventDestroy(sl.resolved);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.side) { (void)hipStreamSynchronize(sl.side); (void)hipStreamDestroy(sl.side); }
+    }
     for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -445,23 +456,48 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     hipEvent_t e0 = ring ? ctx->ring[ctx->ring_used] : ctx->ev_start, e1 = ring ? ctx->ring[ctx->ring_used + 1] : ctx->ev_stop;
     const int kmode = p->mode == PT_MODE_REFERENCE_PACKET ? PT_KMODE_PACKET : (p->mode == PT_MODE_REFERENCE ? PT_KMODE_REFERENCE : PT_KMODE_PATH);
     if (kmode == PT_KMODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL)) {
-        const uint32_t grid = uint32_t(ctx->num_cus > 0 ? ctx->num_cus : 256) * uint32_t(ptk::megakernel_blocks_per_cu());
+        const uint32_t grid = ptk::megakernel_grid(ctx->num_cus > 0 ? ctx->num_cus : 256);
+        const uint32_t grid_lanes = grid * ptk::megakernel_block();
         A.num_batches = A.num_tiles * p->spp;
         A.perm_cols = (A.num_batches + 63u) / 64u;
         A.total_items = A.perm_cols * 64u * 64u;
-        A.chunk_items = tune("PT_TUNE_CHUNK", 256u);
+        A.chunk_items = tune("PT_TUNE_CHUNK", 512u);
         A.shade_threshold = tune("PT_TUNE_SHADE", PT_SHADE_THRESHOLD); A.fill_threshold = tune("PT_TUNE_FILL", PT_FILL_THRESHOLD);
         A.flush_threshold = tune("PT_TUNE_FLUSH", PT_FLUSH_THRESHOLD); A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES);
-        PT_HIP(ctx, ctx->d_samples.ensure(size_t(A.num_batches) * 64u));
-        PT_HIP(ctx, ctx->d_spill.ensure(size_t(grid) * 256u * size_t(64 - PT_SHORT_STACK)));
-        A.samples = ctx->d_samples.ptr; A.queue = ctx->d_queue.ptr; A.spill = ctx->d_spill.ptr;
-        A.cont_capacity = grid * 256u;
-        PT_HIP(ctx, ctx->d_cont.ensure(size_t(A.cont_capacity) * 4u * 2u));
-        A.cont_out = ctx->d_cont.ptr;
-        if (stats) { PT_HIP(ctx, ctx->d_wave_times.ensure(size_t(grid) * 4u * 16u)); PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(grid) * 4u * 16u * 8u, ctx->stream)); A.wave_times = ctx->d_wave_times.ptr; ctx->wave_times_n = grid * 4u; }
-        // timing ring: events tightly around the dominant kernel; otherwise around the whole pass
+        // frame slot (instrumented launches always use slot 0 and are not overlapped)
+        int want_slots = int(tune("PT_TUNE_SLOTS", PT_FRAME_SLOTS));
+        if (want_slots < 1) want_slots = 1;
+        if (want_slots > PtContext::kMaxSlots) want_slots = PtContext::kMaxSlots;
+        ctx->num_slots = want_slots;
+        PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(want_slots))];
+        if (!sl.side) {
+            PT_HIP(ctx, hipStreamCreateWithFlags(&sl.side, hipStreamNonBlocking));
+            PT_HIP(ctx, hipEventCreateWithFlags(&sl.resolved, hipEventDisableTiming));
+            PT_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        }
+        PT_HIP(ctx, sl.queue.ensure(16));
+        PT_HIP(ctx, sl.samples.ensure(size_t(A.num_batches) * 64u));
+        PT_HIP(ctx, sl.spill.ensure(size_t(grid_lanes) * size_t(64 - PT_SHORT_STACK)));
+        A.cont_capacity = grid_lanes;
+        PT_HIP(ctx, sl.cont.ensure(A.cont_passes ? size_t(A.cont_capacity) * 4u * 2u : 4u));
+        A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.cont_out = sl.cont.ptr;
+        if (stats) {
+            const uint32_t waves = grid_lanes / 64u;
+            PT_HIP(ctx, ctx->d_wave_times.ensure(size_t(waves) * 16u));
+            PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(waves) * 16u * 8u, ctx->stream));
+            A.wave_times = ctx->d_wave_times.ptr; ctx->wave_times_n = waves;
+        }
+        // Dependencies: scene uploads are host-synchronous, so the trace only has to wait for the resolve
+        // that last read this slot's sample buffer (NOT for the previous frame's resolve -- that is what
+        // lets consecutive frames overlap); the resolve on the main stream waits for the trace.
         if (!ring) PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
-        PT_HIP(ctx, ptk::launch_megakernel(A, stats, grid, ctx->stream, ring ? e0 : nullptr, ring ? e1 : nullptr));
+        if (sl.used) PT_HIP(ctx, hipStreamWaitEvent(sl.side, sl.resolved, 0));
+        // timing ring: events tightly around the trace kernels on the stream they run on
+        PT_HIP(ctx, ptk::launch_trace(A, stats, grid, sl.side, ring ? e0 : nullptr, ring ? e1 : nullptr));
+        PT_HIP(ctx, hipEventRecord(sl.done, sl.side));
+        PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.done, 0));
+        PT_HIP(ctx, ptk::launch_resolve(A, ctx->stream));
+        PT_HIP(ctx, hipEventRecord(sl.resolved, ctx->stream)); sl.used = true;
         if (!ring) PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
     } else {
         PT_HIP(ctx, hipEventRecord(e0, ctx->stream));

@@ -14,8 +14,14 @@
 #ifndef PT_MEGA_WAVES_PER_SIMD
 #define PT_MEGA_WAVES_PER_SIMD 5   // resident 256-thread blocks per CU = waves per SIMD
 #endif
+#ifndef PT_FRAME_SLOTS
+#define PT_FRAME_SLOTS 6            // frames whose trace phases may be in flight at once (side streams)
+#endif
+#ifndef PT_MEGA_BLOCK
+#define PT_MEGA_BLOCK 64           // threads per workgroup of the persistent kernel: single-wave groups free their CU slot as soon as the wave drains
+#endif
 #ifndef PT_SHADE_THRESHOLD
-#define PT_SHADE_THRESHOLD 16      // shade when this many lanes of a wavefront wait with a finished ray
+#define PT_SHADE_THRESHOLD 8       // shade when this many lanes of a wavefront wait with a finished ray
 #endif
 #ifndef PT_FLUSH_THRESHOLD
 #define PT_FLUSH_THRESHOLD 32      // once the queue is dry, a wavefront with fewer live lanes hands its paths to the next pass
@@ -24,7 +30,7 @@
 #define PT_MAX_CONT_PASSES 0       // continuation passes after pass 0 (the last one runs every path to its end)
 #endif
 #ifndef PT_FILL_THRESHOLD
-#define PT_FILL_THRESHOLD 16       // regenerate when this many lanes of a wavefront are without a path
+#define PT_FILL_THRESHOLD 8        // regenerate when this many lanes of a wavefront are without a path
 #endif
 
 namespace ptk {
@@ -68,9 +74,11 @@ struct RenderArgs {
 };
 
 hipError_t launch_render(const RenderArgs& args, int kmode, bool stats, hipStream_t stream);
-// k0/k1 (optional): events recorded immediately around the dominant trace_paths_kernel
-hipError_t launch_megakernel(const RenderArgs& args, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1);
-int megakernel_blocks_per_cu();
+// k0/k1 (optional): events recorded immediately around the trace_paths_kernel launches
+hipError_t launch_trace(const RenderArgs& args, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1);
+hipError_t launch_resolve(const RenderArgs& args, hipStream_t stream);
+uint32_t megakernel_grid(int num_cus);
+uint32_t megakernel_block();
 hipError_t launch_lbvh2(uint32_t* bvh2, const float* tris9, const uint32_t* morton, const uint32_t* tri_index,
                         uint32_t* parent, uint32_t* flags, uint32_t num_tris, hipStream_t stream);
 hipError_t launch_deinterleave(const float4* gathered, uint64_t stride_px, float4* full, uint32_t width, uint32_t height,

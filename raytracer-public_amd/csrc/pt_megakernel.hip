@@ -44,12 +44,12 @@ constexpr uint32_t kShadowBit = 1u << 16, kContBit = 1u << 17;
 // CONT = false: pass 0, items are pixel-samples generated from the permuted batch queue.
 // CONT = true : continuation pass, items are path records flushed by the previous pass.
 template <bool STATS, bool CONT>
-__global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kernel(const RenderArgs A) {
-    __shared__ unsigned long long lds_stack[4][kShort][64];
+__global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kernel(const RenderArgs A) {
+    __shared__ unsigned long long lds_stack[PT_MEGA_BLOCK / 64][kShort][64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     unsigned long long* const stk = &lds_stack[wave][0][lane];          // entry i at stk[i * 64]: (tmin bits << 32) | ref
-    unsigned long long* const spill = (unsigned long long*)A.spill + ((size_t)blockIdx.x * 256u + threadIdx.x);   // entry j at spill[j * spill_stride]
-    const size_t spill_stride = (size_t)gridDim.x * 256u;
+    unsigned long long* const spill = (unsigned long long*)A.spill + ((size_t)blockIdx.x * PT_MEGA_BLOCK + threadIdx.x);   // entry j at spill[j * spill_stride]
+    const size_t spill_stride = (size_t)gridDim.x * PT_MEGA_BLOCK;
 
     const F3 base = f3(0.9f, 0.7f, 0.3f);
     const F3 L = light_dir();
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kerne
     }
     if (STATS) {
         if (!CONT && A.wave_times && lane == 0) {
-            unsigned long long* w = A.wave_times + ((size_t)blockIdx.x * 4u + wave) * 16u;
+            unsigned long long* w = A.wave_times + ((size_t)blockIdx.x * (PT_MEGA_BLOCK / 64) + wave) * 16u;
             w[0] = t_begin; w[1] = t_qempty; w[2] = wall_clock64(); w[3] = n_iter; w[4] = n_shade; w[5] = n_fill;
             w[6] = n_iter_q; w[7] = lanes_sum; w[8] = lanes_sum_q; w[9] = leaf_lanes;
             w[10] = cy_shade; w[11] = cy_fill; w[12] = cy_step; w[13] = cy_step_q;
@@ -392,7 +392,9 @@ __global__ __launch_bounds__(256) void prefill_samples_kernel(float4* __restrict
         samples[i] = make_float4(v, v, v, 1.0f);
 }
 
-hipError_t launch_megakernel(const RenderArgs& A0, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1) {
+// Trace phase of one frame (prefill + pass 0 + continuation passes) on `stream`; k0/k1 (optional)
+// are recorded immediately around the trace_paths_kernel launches.
+hipError_t launch_trace(const RenderArgs& A0, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1) {
     RenderArgs A = A0;
     // control block: [0] item cursor pass 0, [1..] cursors of the continuation passes, [8], [9] record counts (ping-pong)
     hipError_t e = hipMemsetAsync(A.queue, 0, 16 * sizeof(uint32_t), stream);
@@ -408,8 +410,8 @@ hipError_t launch_megakernel(const RenderArgs& A0, bool stats, uint32_t grid_blo
     A.queue = ctrl; A.cont_out = rec_a; A.cont_out_count = ctrl + 8;
     A.flush_threshold = passes > 0 ? A0.flush_threshold : 0u;
     if (k0) { e = hipEventRecord(k0, stream); if (e != hipSuccess) return e; }
-    if (stats) hipLaunchKernelGGL((trace_paths_kernel<true, false>), dim3(grid_blocks), dim3(256), 0, stream, A);
-    else       hipLaunchKernelGGL((trace_paths_kernel<false, false>), dim3(grid_blocks), dim3(256), 0, stream, A);
+    if (stats) hipLaunchKernelGGL((trace_paths_kernel<true, false>), dim3(grid_blocks), dim3(PT_MEGA_BLOCK), 0, stream, A);
+    else       hipLaunchKernelGGL((trace_paths_kernel<false, false>), dim3(grid_blocks), dim3(PT_MEGA_BLOCK), 0, stream, A);
     e = hipGetLastError(); if (e != hipSuccess) return e;
     // continuation passes: each record advances by at least one closest ray per pass; the last pass never flushes
     for (uint32_t pass = 1; pass <= passes; ++pass) {
@@ -419,17 +421,23 @@ hipError_t launch_megakernel(const RenderArgs& A0, bool stats, uint32_t grid_blo
         A.cont_out = odd ? rec_b : rec_a; A.cont_out_count = ctrl + (odd ? 9 : 8);
         A.flush_threshold = (pass < passes) ? (A0.flush_threshold >> pass) : 0u;
         if (pass >= 2) { e = hipMemsetAsync(A.cont_out_count, 0, sizeof(uint32_t), stream); if (e != hipSuccess) return e; }
-        const uint32_t g = grid_blocks;
-        if (stats) hipLaunchKernelGGL((trace_paths_kernel<true, true>), dim3(g), dim3(256), 0, stream, A);
-        else       hipLaunchKernelGGL((trace_paths_kernel<false, true>), dim3(g), dim3(256), 0, stream, A);
+        if (stats) hipLaunchKernelGGL((trace_paths_kernel<true, true>), dim3(grid_blocks), dim3(PT_MEGA_BLOCK), 0, stream, A);
+        else       hipLaunchKernelGGL((trace_paths_kernel<false, true>), dim3(grid_blocks), dim3(PT_MEGA_BLOCK), 0, stream, A);
         e = hipGetLastError(); if (e != hipSuccess) return e;
     }
     if (k1) { e = hipEventRecord(k1, stream); if (e != hipSuccess) return e; }   // k0..k1 = all trace_paths passes
+    return hipSuccess;
+}
+
+hipError_t launch_resolve(const RenderArgs& A, hipStream_t stream) {
+    if (A.total_items == 0u) return hipSuccess;
     const uint32_t n = A.num_tiles * 64u;
     hipLaunchKernelGGL(resolve_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, A);
     return hipGetLastError();
 }
 
-int megakernel_blocks_per_cu() { return PT_MEGA_WAVES_PER_SIMD; }
+uint32_t megakernel_grid(int num_cus) { return (uint32_t)num_cus * PT_MEGA_WAVES_PER_SIMD * (256 / PT_MEGA_BLOCK); }
+uint32_t megakernel_block() { return PT_MEGA_BLOCK; }
+
 
 } // namespace ptk

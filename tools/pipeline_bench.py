@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Back-to-back frames without host syncs (what bench.py times): ms per frame vs frame slots."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+rt = importlib.import_module("raytracer-public_amd")
+tris = rt.procedural_scene(0, 871414)
+ctx = rt.Context(0); ctx.set_triangles(tris); ctx.build_bvh()
+p = ctx.make_params(1920, 1080, mode=rt.PT_MODE_PATH, spp=4, max_bounces=8)
+for _ in range(8): ctx.render(p)
+ctx.synchronize()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+t0 = time.perf_counter()
+for _ in range(n): ctx.render(p)
+ctx.synchronize()
+dt = time.perf_counter() - t0
+print("slots=%s: %.3f ms/frame, %.0f Msamples/s" % (os.environ.get("PT_TUNE_SLOTS", "default"), dt / n * 1e3, 1920 * 1080 * 4 * n / dt / 1e6))
