@@ -1,0 +1,108 @@
+// PathTracer.js -- Node host class with the API of the reference's src/libs/PathTracer.js,
+// driving libmi355pt (HIP, MI355X) through the N-API addon instead of WebGPU.
+// Node-12-safe CommonJS (no ??, ?., top-level await).  Method names, arity, return shapes and
+// Promise-ness follow the reference (cited per method); the extension options (mode, spp,
+// maxBounces, seed, accumulate) default to the reference's behaviour: one primary ray per pixel.
+"use strict";
+const path = require("path");
+
+let addon = null;
+function native() {
+  if (!addon) addon = require(path.join(__dirname, "..", "napi", "mi355pt.node"));   // throws loudly when not built
+  return addon;
+}
+
+const MODE_REFERENCE_PACKET = 0, MODE_REFERENCE = 1, MODE_PATH = 2;
+
+class PathTracer {
+  // reference: constructor(canvas), PathTracer.js:60-95 -- uses only canvas.width / canvas.height
+  constructor(canvas, options) {
+    this.canvas = canvas;
+    this.device = null;                         // the reference's GPUDevice slot: here the native context handle
+    this.cameraPosition = [0.0, 0.0, 3.5];      // :67
+    this.cameraQuaternion = [0.0, 0.0, 0.0, 1.0];
+    this.buffers = {};                          // kept for shape compatibility; device buffers live in the context
+    this.frameCount = 0;
+    this.trianglesData = new Float32Array([     // default tetrahedron, :79-84
+      1, 1, 1, -1, -1, 1, -1, 1, -1,
+      1, 1, 1, -1, 1, -1, 1, -1, -1,
+      1, 1, 1, 1, -1, -1, -1, -1, 1,
+      -1, -1, 1, 1, -1, -1, -1, 1, -1,
+    ]);
+    const o = options || {};
+    this.options = {
+      device: o.device === undefined ? -1 : o.device,
+      mode: o.mode === undefined ? MODE_REFERENCE : o.mode,
+      spp: o.spp || 1, maxBounces: o.maxBounces || 0, seed: o.seed === undefined ? 1 : o.seed,
+      accumulate: !!o.accumulate, stats: !!o.stats,
+    };
+    this._hasBVH = false;
+  }
+
+  // :97-102 (adapter/device/shaders/buffers/pipelines) -> one native context on one GPU
+  async initialize() {
+    this.device = native().create(this.options.device);
+  }
+
+  computeBVH2Sizing(numTris) { return native().computeBVH2Sizing(numTris); }      // :227
+  computeBVH4Sizing(numNodes4) { return native().computeBVH4Sizing(numNodes4); }  // :234
+
+  buildMortonAndSort(trianglesData) {            // :427 -> { mortonSorted, triIndexSorted }
+    return native().mortonSort(trianglesData);
+  }
+
+  async readBVH2(bytes) {                        // :485 -> fresh Uint32Array copy
+    return native().readBVH2(this.device, bytes);
+  }
+
+  collapseLBVH2ToBVH4(bvh2U32, numTris) {        // :506 -> { bvh4U32, numNodes4 }
+    return native().collapse(bvh2U32, numTris);
+  }
+
+  async buildBVH(trianglesData) {                // :671-749
+    if (!this.device) return;                    // `if (!device) return`, :673
+    const t0 = Date.now();
+    native().setTriangles(this.device, trianglesData);
+    native().buildBVH(this.device);
+    this._hasBVH = true;
+    console.log("BVH Build Time:", Date.now() - t0, "ms");   // :745-748 prints timings
+  }
+
+  async setScene(scene) {                        // :751-754
+    this.trianglesData = scene.getTrianglesFloat32();
+    await this.buildBVH(this.trianglesData);
+  }
+
+  // install a prebuilt BVH (data/BVH2.bin or data/BVH4_wide.bin) instead of rebuilding
+  setBVH2(bvh2U32) { native().setBVH2(this.device, bvh2U32); this._hasBVH = true; }
+  setBVH4(bvh4U32) { native().setBVH4(this.device, bvh4U32); this._hasBVH = true; }
+
+  async render() {                               // :756-822
+    if (!this._hasBVH) return;                   // `if (!this.buffers.BVH) return`, :757
+    const numTriangles = (this.trianglesData.length / 9) | 0;
+    const fov = (70.0 * Math.PI) / 180;          // :761
+    const focal = 1.0 / Math.tan(0.5 * fov);
+    const UBO = new Float32Array([               // :764-787, same 16 floats in the same order
+      this.canvas.width, this.canvas.height, focal, this.canvas.width / this.canvas.height,
+      this.cameraPosition[0], this.cameraPosition[1], this.cameraPosition[2], numTriangles,
+      this.cameraQuaternion[0], this.cameraQuaternion[1], this.cameraQuaternion[2], this.cameraQuaternion[3],
+      this.frameCount, 0, 0, 0,
+    ]);
+    native().render(this.device, UBO, this.options);   // asynchronous on the GPU, like queue.submit (:821)
+  }
+
+  setCameraPosition(x, y, z) { this.cameraPosition = [x, y, z]; }           // :824
+  setCameraQuaternion(x, y, z, w) { this.cameraQuaternion = [x, y, z, w]; } // :828
+  setFrameCount(frameCount) { this.frameCount = frameCount; }               // :832
+
+  // ---- results (the reference presents to a canvas; a Node host reads them back) ----
+  readRadiance() { return native().readRadiance(this.device, this.canvas.width, this.canvas.height); }
+  readRGBA8() { return native().readRGBA8(this.device, this.canvas.width, this.canvas.height); }      // outputTex equivalent, :163-172
+  readTonemapped(fromRGBA8) { return native().readTonemapped(this.device, this.canvas.width, this.canvas.height, fromRGBA8 !== false); }  // tonemapper.wgsl
+  lastRenderMs() { return native().lastRenderMs(this.device); }
+  getStats() { return native().getStats(this.device); }
+  synchronize() { native().synchronize(this.device); }
+  destroy() { if (this.device) { native().destroy(this.device); this.device = null; } }
+}
+
+module.exports = { PathTracer, MODE_REFERENCE_PACKET, MODE_REFERENCE, MODE_PATH, native };

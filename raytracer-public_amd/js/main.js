@@ -1,0 +1,81 @@
+#!/usr/bin/env node
+// main.js -- Node counterpart of the reference's browser driver src/main.js: the same call
+// sequence against the MI355X-native PathTracer (create -> initialize -> Scene.loadGLB ->
+// setScene -> BVH2 dump -> render loop with setCameraPosition / setCameraQuaternion /
+// setFrameCount / render).  Differences forced by the host: no DOM / requestAnimationFrame
+// (a fixed number of frames), the BVH2 dump is written straight to data/BVH2.bin instead of
+// POSTed to /api/write (src/main.js:27-46, src/server/api.js:27-31), and when
+// /assets/dragon.glb is absent (it is not shipped, SURVEY.md 0.3) a procedural dragon-class mesh
+// of the same triangle budget stands in -- the log says so.
+//
+//   node raytracer-public_amd/js/main.js [--frames N] [--width W --height H] [--mode 0|1|2]
+//        [--spp S --bounces B --seed K] [--glb path] [--tris N] [--out frame.ppm] [--dump data/BVH2.bin]
+"use strict";
+const fs = require("fs");
+const path = require("path");
+const PT = require("./PathTracer.js");
+const PTScene = require("./Scene.js");
+
+function arg(name, dflt) { const i = process.argv.indexOf("--" + name); return i >= 0 && i + 1 < process.argv.length ? process.argv[i + 1] : dflt; }
+
+async function main() {
+  const canvas = { width: Number(arg("width", 1920)), height: Number(arg("height", 1080)) };   // index.html:10
+  const mode = Number(arg("mode", PT.MODE_REFERENCE));
+  const pathTracer = new PT.PathTracer(canvas, { mode: mode, spp: Number(arg("spp", 4)), maxBounces: Number(arg("bounces", 8)), seed: Number(arg("seed", 1)) });
+  const camera = { position: [0, 0, 2.5], rotation: [0, 0, 0, 1] };                             // src/main.js:10-14
+
+  await pathTracer.initialize();
+
+  // ---------- Scene ----------
+  const scene = new PTScene.Scene();
+  const glb = arg("glb", "/assets/dragon.glb");
+  try {
+    await scene.loadGLB(glb, { normalize: true, mode: "cube" });                               // src/main.js:20-23
+    console.log("Loaded", glb, "->", scene.getTriangles().length, "triangles");
+  } catch (e) {
+    const n = Number(arg("tris", 871414));
+    console.log("GLB not available (" + glb + "): using the procedural dragon-class stand-in,", n, "triangles");
+    scene.getTrianglesFloat32 = () => PT.native().proceduralScene(0, n, 20260109);
+  }
+  await pathTracer.setScene(scene);
+
+  // ---------- BVH Dump (ONCE) ----------  src/main.js:27-46
+  const numTris = (pathTracer.trianglesData.length / 9) | 0;
+  const bvh2Bytes = pathTracer.computeBVH2Sizing(numTris).bytes;
+  const bvh2U32 = await pathTracer.readBVH2(bvh2Bytes);
+  const dump = arg("dump", path.join("data", "BVH2.bin"));
+  console.log("Uploading BVH2:", bvh2U32.length * 4, "bytes ->", dump);
+  fs.mkdirSync(path.dirname(dump), { recursive: true });
+  PT.native().writeU32File(dump, bvh2U32);
+  console.log("BVH2 dump complete");
+
+  // ---------- Render Loop ----------
+  const frames = Number(arg("frames", 30));
+  let frameIndex = 0;
+  await pathTracer.render(); pathTracer.synchronize();        // warm-up (first-touch allocations)
+  const t0 = Date.now();
+  for (let f = 0; f < frames; f++) {
+    frameIndex++;
+    pathTracer.setCameraPosition(camera.position[0], camera.position[1], camera.position[2]);
+    pathTracer.setCameraQuaternion(camera.rotation[0], camera.rotation[1], camera.rotation[2], camera.rotation[3]);
+    pathTracer.setFrameCount(frameIndex);
+    await pathTracer.render();
+  }
+  pathTracer.synchronize();
+  const sec = (Date.now() - t0) / 1000;
+  const spp = mode === PT.MODE_PATH ? pathTracer.options.spp : 1;
+  console.log((frames / sec).toFixed(1) + " FPS, " + (canvas.width * canvas.height * spp * frames / sec / 1e6).toFixed(1) + " Msamples/s (" + frames + " frames)");
+
+  const out = arg("out", null);
+  if (out) {      // what the tonemapper pass would have put on the canvas (tonemapper.wgsl)
+    const rgba = pathTracer.readTonemapped(true);
+    const header = Buffer.from("P6\n" + canvas.width + " " + canvas.height + "\n255\n");
+    const rgb = Buffer.alloc(canvas.width * canvas.height * 3);
+    for (let i = 0, o = 0; i < rgba.length; i += 4) { rgb[o++] = rgba[i]; rgb[o++] = rgba[i + 1]; rgb[o++] = rgba[i + 2]; }
+    fs.writeFileSync(out, Buffer.concat([header, rgb]));
+    console.log("wrote", out);
+  }
+  pathTracer.destroy();
+}
+
+main().catch((e) => { console.error(e); process.exit(1); });

@@ -1,0 +1,81 @@
+"""The Node host side (raytracer-public_amd/js + the N-API addon over the C ABI)."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+NODE = shutil.which("node")
+ADDON = os.path.join(ROOT, "raytracer-public_amd", "napi", "mi355pt.node")
+
+pytestmark = pytest.mark.skipif(NODE is None or not os.path.exists(ADDON), reason="node or the built addon is missing")
+
+
+def test_addon_host_functions_match_reference_vectors():
+    # same golden vectors as tests/test_host_build.py, through PathTracer.js -> N-API -> C ABI
+    out = subprocess.check_output([NODE, os.path.join(HERE, "js_host_check.js"), os.path.join(HERE, "golden", "pathtracer_js_golden.json")], text=True)
+    assert out.startswith("ok ")
+
+
+def test_scene_js_matches_three_gltfloader():
+    # Scene.loadGLB / parseGLTF / normalizeMesh / getTrianglesFloat32 vs the numbers three's GLTFLoader +
+    # the reference's Scene.js arithmetic produced for the reference's two bundled GLBs
+    got = json.loads(subprocess.check_output([NODE, os.path.join(HERE, "js_scene_check.js")], text=True))
+    gold = json.load(open(os.path.join(HERE, "golden", "glb_golden.json")))
+    assert set(got) == set(gold) == {"dodecahedron.glb", "steve.glb"}
+    for f, g in gold.items():
+        assert got[f]["numTris"] == g["numTris"]
+        assert got[f]["world_bits"] == g["world_f32_bits"]
+        assert got[f]["normalized_bits"] == g["normalized_cube_f32_bits"]
+        assert got[f]["first"] == g["first_world_vertex_f64"]          # even the f64 intermediates agree
+
+
+def test_scene_js_rejects_garbage(tmp_path):
+    bad = tmp_path / "bad.glb"
+    bad.write_bytes(b"not a glb at all, definitely")
+    script = "const {Scene}=require(%r);const l=console.error;console.error=()=>{};new Scene().loadGLB(%r).then(()=>process.exit(1),e=>{console.log('rejected:'+e.message);});" % (
+        os.path.join(ROOT, "raytracer-public_amd", "js", "Scene.js"), str(bad))
+    out = subprocess.check_output([NODE, "-e", script], text=True)
+    assert "rejected:" in out and "GLB" in out
+
+
+@pytest.mark.gpu
+def test_node_driver_end_to_end(tmp_path, orc):
+    """src/main.js call sequence under Node on the GPU: GLB -> setScene -> BVH2 dump -> render; the dumped
+    BVH2 and the rendered reference-mode frame equal the oracle's bit for bit."""
+    import orc as orc_mod
+    glb = os.path.join(HERE, "golden", "steve.glb")
+    dump = str(tmp_path / "data" / "BVH2.bin")
+    script = r"""
+const path=require('path'); const PT=require(%r); const {Scene}=require(%r);
+(async()=>{ const log=console.log; console.log=()=>{};
+ const pt=new PT.PathTracer({width:160,height:96},{mode:PT.MODE_REFERENCE});
+ await pt.initialize(); const s=new Scene(); await s.loadGLB(%r,{normalize:true,mode:'cube'}); await pt.setScene(s);
+ const n=(pt.trianglesData.length/9)|0; const b2=await pt.readBVH2(pt.computeBVH2Sizing(n).bytes);
+ PT.native().writeU32File(%r,b2);
+ pt.setCameraPosition(0.3,0.2,2.5); pt.setCameraQuaternion(0,0,0,1); pt.setFrameCount(7); await pt.render();
+ const img=pt.readRadiance(); const px=pt.readRGBA8();
+ require('fs').writeFileSync(%r, Buffer.from(img.buffer)); require('fs').writeFileSync(%r, Buffer.from(pt.trianglesData.buffer));
+ pt.options.mode=PT.MODE_PATH; pt.options.spp=2; pt.options.maxBounces=3; await pt.render(); const img2=pt.readRadiance();
+ require('fs').writeFileSync(%r, Buffer.from(img2.buffer));
+ log(JSON.stringify({n:n, rgba0:[px[0],px[1],px[2],px[3]]})); pt.destroy(); })().catch(e=>{console.error(e);process.exit(1);});
+""" % (os.path.join(ROOT, "raytracer-public_amd", "js", "PathTracer.js"), os.path.join(ROOT, "raytracer-public_amd", "js", "Scene.js"),
+       glb, dump, str(tmp_path / "img.bin"), str(tmp_path / "tris.bin"), str(tmp_path / "img2.bin"))
+    os.makedirs(os.path.dirname(dump), exist_ok=True)
+    info = json.loads(subprocess.check_output([NODE, "-e", script], text=True).strip().splitlines()[-1])
+    tris = np.fromfile(str(tmp_path / "tris.bin"), np.float32)
+    assert info["n"] == 72 and tris.size == 72 * 9
+    bvh2 = orc.build_lbvh2(tris)
+    assert np.array_equal(np.fromfile(dump, np.uint32), bvh2)                  # data/BVH2.bin == oracle LBVH2
+    bvh4, _ = orc.collapse_bvh4(bvh2, 72)
+    ref, _, _ = orc.render(orc.make_params(160, 96, 72, (0.3, 0.2, 2.5), (0, 0, 0, 1), mode=orc_mod.MODE_SINGLE, frame=7), tris, bvh4)
+    img = np.fromfile(str(tmp_path / "img.bin"), np.float32).reshape(96, 160, 4)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    ref2, _, _ = orc.render(orc.make_params(160, 96, 72, (0.3, 0.2, 2.5), (0, 0, 0, 1), mode=orc_mod.MODE_PATH, spp=2, max_bounces=3, seed=1, frame=7), tris, bvh4)
+    img2 = np.fromfile(str(tmp_path / "img2.bin"), np.float32).reshape(96, 160, 4)
+    assert np.array_equal(img2.view(np.uint32), ref2.view(np.uint32))
+    assert info["rgba0"][3] == 255
