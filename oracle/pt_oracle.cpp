@@ -13,7 +13,7 @@
 // Pinning status:
 //   * f16 codec, Morton+sort, BVH2->BVH4 collapse: pinned against vectors generated
 //     by importing the reference's own src/libs/PathTracer.js under Node
-//     (tests/golden/gen_golden_js.mjs -> tests/golden/*.json).
+//     (tests/golden/gen_golden_js.js -> tests/golden/pathtracer_js_golden.json).
 //   * BVH4_wide promotion: pinned against oracle/_ref/bvh4_wide_ref, the reference's
 //     tests/test.cpp compiled where it lies (oracle/Makefile target `ref`).
 //   * renderer.wgsl / BVHBuilder.wgsl restatements: the WGSL cannot execute in this
@@ -528,6 +528,7 @@ struct Params {   // mirrored in tests as ctypes.Structure
     uint32_t spp, max_bounces, seed;
     uint32_t x0, y0, x1, y1;            // half-open pixel rectangle to render
     uint32_t step_x, step_y;            // pixel subsampling stride (modes 1,2)
+    uint32_t accum_frames;              // mode 2: number of consecutive frames accumulated (0 or 1 = single frame)
 };
 
 // primary ray for pixel position (fx, fy) in pixels, renderer.wgsl:387-395
@@ -732,12 +733,19 @@ int orc_render(const Params* Pp, const float* tris, const uint32_t* bvh4, float*
             o[0] = col.x; o[1] = col.y; o[2] = col.z; o[3] = 1.0f;
             if (tri_ids) tri_ids[size_t(py) * P.width + px] = h.tri;
         } else {
-            V3 sum = v3(0, 0, 0);
-            for (uint32_t s = 0; s < P.spp; s++) {
-                sum = sum + path_sample(sc, P, px, py, P.frame * P.spp + s, st);
-                if (st) st->samples++;
+            // progressive accumulation (BUILD-DEFINED): each frame's samples are summed from zero in
+            // sample order, frame sums are added to the running total in frame order
+            const uint32_t frames = P.accum_frames ? P.accum_frames : 1u;
+            V3 sum = v3(0, 0, 0); float count = 0.0f;
+            for (uint32_t f = 0; f < frames; f++) {
+                V3 fsum = v3(0, 0, 0);
+                for (uint32_t s = 0; s < P.spp; s++) {
+                    fsum = fsum + path_sample(sc, P, px, py, (P.frame + f) * P.spp + s, st);
+                    if (st) st->samples++;
+                }
+                sum = sum + fsum; count = count + float(P.spp);
             }
-            float invn = 1.0f / float(P.spp);
+            float invn = 1.0f / count;
             o[0] = sum.x * invn; o[1] = sum.y * invn; o[2] = sum.z * invn; o[3] = 1.0f;
         }
     }

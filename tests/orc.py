@@ -23,6 +23,7 @@ class Params(C.Structure):
         ("spp", C.c_uint32), ("max_bounces", C.c_uint32), ("seed", C.c_uint32),
         ("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32),
         ("step_x", C.c_uint32), ("step_y", C.c_uint32),
+        ("accum_frames", C.c_uint32),
     ]
 
 
@@ -102,7 +103,7 @@ class Oracle:
 
     # ---- render ------------------------------------------------------
     def make_params(self, width, height, num_tris, cam_pos=(0, 0, 2.5), cam_quat=(0, 0, 0, 1), mode=MODE_SINGLE,
-                    spp=1, max_bounces=0, seed=1, frame=0, rect=None, step=(1, 1)):
+                    spp=1, max_bounces=0, seed=1, frame=0, rect=None, step=(1, 1), accum_frames=1):
         focal, aspect = focal_aspect(width, height)
         p = Params()
         p.width, p.height, p.focal, p.aspect = width, height, float(focal), float(aspect)
@@ -113,6 +114,7 @@ class Oracle:
         x0, y0, x1, y1 = rect if rect else (0, 0, width, height)
         p.x0, p.y0, p.x1, p.y1 = x0, y0, x1, y1
         p.step_x, p.step_y = step
+        p.accum_frames = accum_frames
         return p
 
     def render(self, params, tris, bvh4, want_tri_ids=False):

@@ -166,6 +166,44 @@ def test_tile_sharding_matches_whole_frame(rt, gpu_ctx):
         assert same_bits(got, full), count
 
 
+def test_progressive_accumulation_bit_exact(rt, orc, gpu_ctx):
+    # config C5 in miniature: F frames x spp accumulated into one image
+    tris = rt.procedural_scene(0, 20000)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    bvh4 = gpu_ctx.read_bvh4()
+    w, h, spp, frames = 120, 72, 2, 3
+    for simple in (False, True):
+        for f in range(frames):
+            gpu_ctx.render(gpu_ctx.make_params(w, h, mode=rt.PT_MODE_PATH, spp=spp, max_bounces=4, seed=11, frame=5 + f, accumulate=True, simple_kernel=simple))
+        img = gpu_ctx.read_radiance()
+        ref, _, _ = orc.render(orc.make_params(w, h, tris.size // 9, mode=orc_mod.MODE_PATH, spp=spp, max_bounces=4, seed=11, frame=5, accum_frames=frames), tris, bvh4)
+        assert same_bits(img, ref), simple
+        # a non-accumulating render restarts the running sum
+        gpu_ctx.render(gpu_ctx.make_params(w, h, mode=rt.PT_MODE_PATH, spp=spp, max_bounces=4, seed=11, frame=5, simple_kernel=simple))
+        one, _, _ = orc.render(orc.make_params(w, h, tris.size // 9, mode=orc_mod.MODE_PATH, spp=spp, max_bounces=4, seed=11, frame=5), tris, bvh4)
+        assert same_bits(gpu_ctx.read_radiance(), one)
+
+
+def test_sponza_class_interior_bit_exact(rt, orc, gpu_ctx):
+    # config C4 in miniature: camera inside, every ray hits, long thin triangles -> deep LBVH
+    tris = rt.procedural_scene(1, 30000)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    bvh4 = gpu_ctx.read_bvh4()
+    cam, quat = (0.55, -0.05, 0.05), quat_yaw_pitch(1.45, 0.05)
+    w, h = 128, 72
+    gpu_ctx.render(gpu_ctx.make_params(w, h, cam, quat, mode=rt.PT_MODE_PATH, spp=2, max_bounces=8, seed=3, stats=True))
+    img = gpu_ctx.read_radiance(); st = gpu_ctx.stats()
+    ref, _, ost = orc.render(orc.make_params(w, h, tris.size // 9, cam, quat, mode=orc_mod.MODE_PATH, spp=2, max_bounces=8, seed=3), tris, bvh4)
+    assert same_bits(img, ref)
+    assert st["rays_closest"] == ost["rays_closest"] and st["nodes_examined"] == ost["nodes_examined"] and st["max_stack"] == ost["max_stack"]
+    gpu_ctx.render(gpu_ctx.make_params(w, h, cam, quat, mode=rt.PT_MODE_REFERENCE))
+    ref1, ids, _ = orc.render(orc.make_params(w, h, tris.size // 9, cam, quat, mode=orc_mod.MODE_SINGLE), tris, bvh4, want_tri_ids=True)
+    assert same_bits(gpu_ctx.read_radiance(), ref1)
+    assert (ids != 0xFFFFFFFF).mean() > 0.99       # interior: (almost) every camera ray hits
+
+
 def test_error_paths(rt, gpu_ctx):
     fresh = rt.Context(0)
     with pytest.raises(rt.PtError) as e:
