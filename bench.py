@@ -83,8 +83,9 @@ def main():
     width, height = args.width, args.height
     tris = rt.procedural_scene(rt.SCENE_DRAGON_CLASS, NUM_TRIS, SCENE_SEED)
     ctx = rt.Context(device)
-    stream = torch.cuda.Stream(device=device)
-    ctx.set_stream(stream.cuda_stream)
+    # the context's own non-blocking stream, made visible to torch so that the RCCL gather (which orders
+    # itself against torch's current stream) follows the render / resolve kernels
+    stream = torch.cuda.ExternalStream(ctx.get_stream(), device=device)
     ctx.set_triangles(tris)
     ctx.build_bvh()                  # Morton+sort, LBVH2 kernels, collapse: data/BVH2.bin equivalent
 

@@ -99,6 +99,9 @@ const char* pt_version(void);
  * stream) instead of the context's own stream.  NULL restores the own stream. */
 int  pt_set_stream(PtContext* ctx, void* hip_stream);
 int  pt_synchronize(PtContext* ctx);
+/* The hipStream_t the context currently issues on (its own non-blocking stream unless pt_set_stream
+ * replaced it) -- e.g. to wrap it as torch.cuda.ExternalStream so collectives order after the render. */
+int  pt_get_stream(PtContext* ctx, void** hip_stream);
 
 /* ---- host-side scene build (no GPU touched; the reference runs these in JS) ------------ */
 

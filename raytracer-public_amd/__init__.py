@@ -55,7 +55,7 @@ class PtStats(C.Structure):
 
 # every symbol include/mi355pt.h declares (tests/test_abi.py checks the header against this)
 EXPORTS = [
-    "pt_create", "pt_destroy", "pt_last_error", "pt_version", "pt_set_stream", "pt_synchronize",
+    "pt_create", "pt_destroy", "pt_last_error", "pt_version", "pt_set_stream", "pt_get_stream", "pt_synchronize",
     "pt_compute_bvh2_sizing", "pt_compute_bvh4_sizing", "pt_morton_sort", "pt_collapse_lbvh2_to_bvh4",
     "pt_bvh2_to_bvh4_wide", "pt_file_write_u32", "pt_file_read_u32", "pt_scene_procedural",
     "pt_set_triangles", "pt_build_bvh", "pt_build_lbvh2", "pt_read_bvh2", "pt_set_bvh4", "pt_set_bvh2",
@@ -186,6 +186,11 @@ class Context:
 
     def set_stream(self, stream_handle):
         self._ck(lib.pt_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def get_stream(self):
+        p = C.c_void_p()
+        self._ck(lib.pt_get_stream(self.h, C.byref(p)))
+        return p.value
 
     def synchronize(self):
         self._ck(lib.pt_synchronize(self.h))

@@ -180,6 +180,12 @@ int pt_set_stream(PtContext* ctx, void* hip_stream) {
     return PT_OK;
 }
 
+int pt_get_stream(PtContext* ctx, void** hip_stream) {
+    if (!ctx || !hip_stream) return fail(ctx, PT_ERR_INVALID_ARG, "pt_get_stream: null argument");
+    *hip_stream = (void*)ctx->stream;
+    return PT_OK;
+}
+
 int pt_synchronize(PtContext* ctx) {
     if (int rc = bind(ctx)) return rc;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));

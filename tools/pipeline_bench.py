@@ -2,15 +2,23 @@
 """Back-to-back frames without host syncs (what bench.py times): ms per frame vs frame slots."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+if os.environ.get("PB_TORCH"):
+    import torch
 rt = importlib.import_module("raytracer-public_amd")
 tris = rt.procedural_scene(0, 871414)
-ctx = rt.Context(0); ctx.set_triangles(tris); ctx.build_bvh()
+ctx = rt.Context(0)
+if os.environ.get("PB_TORCH") == "2":
+    st = torch.cuda.Stream(); ctx.set_stream(st.cuda_stream)
+ctx.set_triangles(tris); ctx.build_bvh()
 p = ctx.make_params(1920, 1080, mode=rt.PT_MODE_PATH, spp=4, max_bounces=8)
 for _ in range(8): ctx.render(p)
 ctx.synchronize()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+if os.environ.get("PB_RING"): ctx.timing_begin(n)
 t0 = time.perf_counter()
 for _ in range(n): ctx.render(p)
 ctx.synchronize()
 dt = time.perf_counter() - t0
+if os.environ.get("PB_RING"):
+    ms = ctx.timing_collect(n); print("ring: kernel avg %.3f ms" % ms.mean())
 print("slots=%s: %.3f ms/frame, %.0f Msamples/s" % (os.environ.get("PT_TUNE_SLOTS", "default"), dt / n * 1e3, 1920 * 1080 * 4 * n / dt / 1e6))
