@@ -248,7 +248,10 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
             const uint32_t ti = S.cur & 0x7fffffffu;
             const bool tri_ok = ti < A.num_tris;
             const uint4* rec = at_leaf ? (const uint4*)(A.tris + (size_t)(tri_ok ? ti : 0u) * 3) : (A.nodes + (size_t)S.cur * 4);
-            const uint4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+            uint4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+            // keep the four loads here: without this the compiler sinks them into the two branches again
+            asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z), "+v"(n1.w),
+                              "+v"(n2.x), "+v"(n2.y), "+v"(n2.z), "+v"(n2.w), "+v"(n3.x), "+v"(n3.y), "+v"(n3.z), "+v"(n3.w));
             if (at_leaf) {
                 if (tri_ok) {
                     const float4 a = make_float4(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z), __uint_as_float(n0.w));
