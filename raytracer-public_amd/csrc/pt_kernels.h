@@ -9,10 +9,10 @@
 
 // megakernel tuning knobs (overridable with -D at build time)
 #ifndef PT_SHORT_STACK
-#define PT_SHORT_STACK 16          // LDS stack entries per lane (8 B each); deeper entries spill to global scratch
+#define PT_SHORT_STACK 12          // LDS stack entries per lane (8 B each); deeper entries spill to global scratch
 #endif
 #ifndef PT_MEGA_WAVES_PER_SIMD
-#define PT_MEGA_WAVES_PER_SIMD 5   // resident 256-thread blocks per CU = waves per SIMD
+#define PT_MEGA_WAVES_PER_SIMD 6   // resident 256-thread blocks per CU = waves per SIMD
 #endif
 #ifndef PT_FRAME_SLOTS
 #define PT_FRAME_SLOTS 6            // frames whose trace phases may be in flight at once (side streams)
