@@ -469,7 +469,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         A.total_items = A.perm_cols * 64u * 64u;
         A.chunk_items = tune("PT_TUNE_CHUNK", 512u);
         A.shade_threshold = tune("PT_TUNE_SHADE", PT_SHADE_THRESHOLD); A.fill_threshold = tune("PT_TUNE_FILL", PT_FILL_THRESHOLD);
-        A.flush_threshold = tune("PT_TUNE_FLUSH", PT_FLUSH_THRESHOLD); A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES);
+        A.flush_threshold = tune("PT_TUNE_FLUSH", PT_FLUSH_THRESHOLD); A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES); A.drop_cont = tune("PT_TUNE_DROPCONT", 0u);
         // frame slot (instrumented launches always use slot 0 and are not overlapped)
         int want_slots = int(tune("PT_TUNE_SLOTS", PT_FRAME_SLOTS));
         if (want_slots < 1) want_slots = 1;

@@ -71,6 +71,7 @@ struct RenderArgs {
     const float4* cont_in; const uint32_t* cont_in_count;
     uint32_t  cont_capacity, flush_threshold, cont_passes;
     uint32_t  shade_threshold, fill_threshold;
+    uint32_t  drop_cont;        // timing experiments only: discard flushed paths (wrong image)
 };
 
 hipError_t launch_render(const RenderArgs& args, int kmode, bool stats, hipStream_t stream);

@@ -417,7 +417,7 @@ hipError_t launch_trace(const RenderArgs& A0, bool stats, uint32_t grid_blocks, 
     else       hipLaunchKernelGGL((trace_paths_kernel<false, false>), dim3(grid_blocks), dim3(PT_MEGA_BLOCK), 0, stream, A);
     e = hipGetLastError(); if (e != hipSuccess) return e;
     // continuation passes: each record advances by at least one closest ray per pass; the last pass never flushes
-    for (uint32_t pass = 1; pass <= passes; ++pass) {
+    for (uint32_t pass = 1; pass <= passes && !A0.drop_cont; ++pass) {
         const bool odd = (pass & 1u) != 0u;
         A.queue = ctrl + pass;
         A.cont_in = odd ? rec_a : rec_b; A.cont_in_count = ctrl + (odd ? 8 : 9);

@@ -1,0 +1,141 @@
+"""Edge cases the reference handles explicitly (empty scene, single triangle, odd sizes) and the
+full-size configurations through size-independent properties."""
+import numpy as np
+import pytest
+
+import orc as orc_mod
+from scenes import TETRA, random_soup
+
+pytestmark = pytest.mark.gpu
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def test_empty_scene_renders_background(rt, gpu_ctx):
+    # numTris == 0: BVH[0] = 0, every ray misses (renderer.wgsl:224, PathTracer.js:701-707)
+    gpu_ctx.set_triangles(np.zeros(0, np.float32))
+    gpu_ctx.build_bvh()
+    assert gpu_ctx.scene_info() == {"numTris": 0, "numNodes2": 0, "numNodes4": 0}
+    assert np.array_equal(gpu_ctx.read_bvh4(), np.array([0], np.uint32))
+    for mode in (rt.PT_MODE_REFERENCE_PACKET, rt.PT_MODE_REFERENCE, rt.PT_MODE_PATH):
+        gpu_ctx.render(gpu_ctx.make_params(40, 24, mode=mode, spp=2, max_bounces=2))
+        img = gpu_ctx.read_radiance()
+        assert np.all(img[..., :3] == np.float32(0.01)) and np.all(img[..., 3] == 1.0)
+
+
+def test_single_triangle_root_leaf(rt, orc, gpu_ctx):
+    tris = np.array([-1, -1, 0, 1, -1, 0, 0, 1, 0], np.float32)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    bvh4 = gpu_ctx.read_bvh4()
+    assert bvh4[0] == 1 and (bvh4[8] & 0x80000000)        # the root is the only node and it is a leaf
+    for mode, omode in ((rt.PT_MODE_REFERENCE_PACKET, orc_mod.MODE_PACKET), (rt.PT_MODE_REFERENCE, orc_mod.MODE_SINGLE), (rt.PT_MODE_PATH, orc_mod.MODE_PATH)):
+        gpu_ctx.render(gpu_ctx.make_params(50, 30, mode=mode, spp=2, max_bounces=2, seed=2))
+        ref, _, _ = orc.render(orc.make_params(50, 30, 1, mode=omode, spp=2, max_bounces=2, seed=2), tris, bvh4)
+        assert same_bits(gpu_ctx.read_radiance(), ref)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (9, 17), (257, 131)])
+def test_odd_resolutions(rt, orc, gpu_ctx, w, h):
+    tris = random_soup(600, 4)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    bvh4 = gpu_ctx.read_bvh4()
+    for mode, omode in ((rt.PT_MODE_REFERENCE_PACKET, orc_mod.MODE_PACKET), (rt.PT_MODE_REFERENCE, orc_mod.MODE_SINGLE), (rt.PT_MODE_PATH, orc_mod.MODE_PATH)):
+        gpu_ctx.render(gpu_ctx.make_params(w, h, mode=mode, spp=3, max_bounces=2, seed=8))
+        ref, _, _ = orc.render(orc.make_params(w, h, 600, mode=omode, spp=3, max_bounces=2, seed=8), tris, bvh4)
+        assert same_bits(gpu_ctx.read_radiance(w, h), ref), (mode, w, h)
+
+
+def test_num_tris_smaller_than_uploaded(rt, orc, gpu_ctx):
+    # the UBO's numTris gates leaf tests (`ti < numTris`, renderer.wgsl:267): triangles past it are invisible
+    tris = random_soup(500, 6)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    bvh4 = gpu_ctx.read_bvh4()
+    gpu_ctx.render(gpu_ctx.make_params(96, 64, mode=rt.PT_MODE_REFERENCE, num_tris=200))
+    ref, _, _ = orc.render(orc.make_params(96, 64, 200, mode=orc_mod.MODE_SINGLE), tris, bvh4)
+    assert same_bits(gpu_ctx.read_radiance(), ref)
+
+
+def test_rgba8_and_tonemap_match_oracle(rt, orc, gpu_ctx):
+    tris = rt.procedural_scene(0, 20000)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    gpu_ctx.render(gpu_ctx.make_params(160, 90, mode=rt.PT_MODE_REFERENCE))
+    img = gpu_ctx.read_radiance()
+    want8 = np.floor(np.clip(img, 0, 1) * 255 + 0.5).astype(np.uint8)             # rgba8unorm store
+    assert np.array_equal(gpu_ctx.read_rgba8(), want8)
+    tm = gpu_ctx.read_tonemapped(True).astype(np.int32)
+    ref = orc.tonemap(img, quantize=True).astype(np.int32)                          # tonemapper.wgsl + vertical flip
+    assert np.abs(tm - ref).max() <= 1                                              # powf: 1 LSB tolerance, f32 pow is not pinned
+
+
+@pytest.fixture(scope="module")
+def full_scene(rt, gpu_ctx_full):
+    return gpu_ctx_full
+
+
+@pytest.fixture(scope="module")
+def gpu_ctx_full(rt):
+    ctx = rt.Context(0)
+    tris = rt.procedural_scene(0, 871414)
+    ctx.set_triangles(tris)
+    ctx.build_bvh()
+    ctx._tris = tris
+    yield ctx
+    ctx.close()
+
+
+def test_full_size_c2_properties(rt, orc, gpu_ctx_full):
+    """BASELINE config C2 at full size: determinism, kernel A/B equality, oracle agreement on a pixel
+    subsample, counter consistency, BVH invariants."""
+    ctx = gpu_ctx_full
+    tris = ctx._tris
+    info = ctx.scene_info()
+    assert info["numTris"] == 871414 and info["numNodes2"] == 2 * 871414 - 1
+    bvh2, bvh4 = ctx.read_bvh2(), ctx.read_bvh4()
+    assert bvh4[0] == info["numNodes4"] and 871414 < info["numNodes4"] <= 2 * 871414 - 1
+    leaves = bvh4[8::8] & 0x80000000 != 0
+    assert leaves.sum() == 871414                                                  # one leaf per triangle
+    assert np.array_equal(np.sort(bvh4[8::8][leaves] & 0x7FFFFFFF), np.arange(871414, dtype=np.uint32))
+    w, h = 1920, 1080
+    kw = dict(mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, seed=1)
+    ctx.render(ctx.make_params(w, h, stats=True, **kw)); a = ctx.read_radiance().copy(); st = ctx.stats()
+    ctx.render(ctx.make_params(w, h, **kw)); b = ctx.read_radiance().copy()
+    ctx.render(ctx.make_params(w, h, simple_kernel=True, **kw)); c = ctx.read_radiance().copy()
+    assert same_bits(a, b) and same_bits(a, c)                                      # deterministic; both kernels agree
+    assert st["samples"] == w * h * 4 and st["rays_closest"] >= st["samples"] and st["stack_drops"] == 0
+    # oracle on every 16th pixel in x and y (8100 pixels x 4 spp): bit-exact
+    ref, _, ost = orc.render(orc.make_params(w, h, 871414, mode=orc_mod.MODE_PATH, spp=4, max_bounces=8, seed=1, step=(16, 16)), tris, bvh4)
+    assert same_bits(a[::16, ::16], ref[::16, ::16])
+    assert np.isfinite(a).all() and a[..., :3].min() >= 0.0
+
+
+def test_full_size_c3_bvh4_wide(rt, orc, gpu_ctx_full):
+    # config C3's input: BVH4_wide of the same BVH2 (M = 2N-1 nodes): closest hits identical to the collapsed BVH4
+    ctx = gpu_ctx_full
+    bvh2 = ctx.read_bvh2()
+    collapsed = ctx.read_bvh4().copy()
+    ctx.render(ctx.make_params(960, 540, mode=rt.PT_MODE_REFERENCE)); ref = ctx.read_radiance().copy()
+    wide = rt.bvh2_to_bvh4_wide(bvh2)
+    assert wide[0] == 2 * 871414 - 1
+    ctx.set_bvh4(wide)
+    ctx.render(ctx.make_params(960, 540, mode=rt.PT_MODE_REFERENCE)); got = ctx.read_radiance().copy()
+    ctx.set_bvh4(collapsed)
+    diff = (got.view(np.uint32) != ref.view(np.uint32)).any(axis=2).mean()
+    assert diff < 1e-4                                                              # same closest hit except exact-t ties
+
+
+def test_full_size_c5_4k_accumulate_smoke(rt, gpu_ctx_full):
+    # config C5 shape: 3840x2160, 4 spp per frame, 16 bounces, accumulated over frames (2 here)
+    ctx = gpu_ctx_full
+    for f in range(2):
+        ctx.render(ctx.make_params(3840, 2160, mode=rt.PT_MODE_PATH, spp=4, max_bounces=16, seed=1, frame=f, accumulate=True))
+    img = ctx.read_radiance()
+    assert img.shape == (2160, 3840, 4) and np.isfinite(img).all()
+    assert (img[..., 0] > 0.011).mean() > 0.08                                     # the object is there
+    ms = ctx.last_render_ms()
+    assert ms > 0
