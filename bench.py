@@ -50,6 +50,29 @@ def cpu_baseline(tris, bvh4):
                       % (st["samples"], dt, os.cpu_count() or 0)}, st
 
 
+def cpu_baseline_node(tris, bvh4):
+    """The same loop as a single-thread Node/JS program (oracle/js/pt_oracle.js, bit-identical to the C++
+    oracle): every 2nd pixel in x and y of the same frame."""
+    import shutil, subprocess, tempfile
+    import numpy as np
+    node = shutil.which("node")
+    if node is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc as orc_mod
+    focal, aspect = orc_mod.focal_aspect(WIDTH, HEIGHT)
+    with tempfile.TemporaryDirectory() as d:
+        np.ascontiguousarray(tris, np.float32).tofile(os.path.join(d, "t")); np.ascontiguousarray(bvh4, np.uint32).tofile(os.path.join(d, "b"))
+        P = dict(width=WIDTH, height=HEIGHT, focal=float(focal), aspect=float(aspect), camPos=[0, 0, 2.5], camQuat=[0, 0, 0, 1], frame=0, mode=2,
+                 spp=SPP, maxBounces=BOUNCES, seed=SEED, numTris=NUM_TRIS, stepX=2, stepY=2)
+        json.dump(P, open(os.path.join(d, "p"), "w"))
+        info = json.loads(subprocess.check_output([node, os.path.join(ROOT, "oracle", "js", "pt_oracle.js"), os.path.join(d, "t"), os.path.join(d, "b"),
+                                                   os.path.join(d, "p"), os.path.join(d, "o")], text=True))
+    return {"value": round(info["stats"]["samples"] / info["seconds"] / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "every 2nd pixel in x and y of the same frame (%d samples, %.1f s), oracle/js/pt_oracle.js on Node %s, single thread"
+                      % (info["stats"]["samples"], info["seconds"], info["node"])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,8 +228,10 @@ def main():
                          "counters": {k: my_stats[k] for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples")}},
         }
         if world == 1 and not args.no_cpu_baseline and (width, height) == (WIDTH, HEIGHT):
-            base, ost = cpu_baseline(tris, ctx.read_bvh4())
+            bvh4 = ctx.read_bvh4()
+            base, ost = cpu_baseline(tris, bvh4)
             out["cpu_baseline"] = base
+            out["cpu_baseline_node"] = cpu_baseline_node(tris, bvh4)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
