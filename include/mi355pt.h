@@ -73,7 +73,8 @@ typedef struct PtRenderParams {
 
 enum {
     PT_FLAG_STATS = 1u,          /* run the instrumented kernel variant and fill PtStats */
-    PT_FLAG_SIMPLE_KERNEL = 2u   /* PT_MODE_PATH: one-pixel-per-lane kernel instead of the persistent megakernel (A/B checks) */
+    PT_FLAG_SIMPLE_KERNEL = 2u,  /* PT_MODE_PATH: one-pixel-per-lane kernel instead of the persistent megakernel (A/B checks) */
+    PT_FLAG_BRUTE_FORCE = 4u     /* modes 1, 2: ignore the BVH, test every triangle and every sphere of pt_set_spheres (config C1) */
 };
 
 /* Traversal counters of the last PT_FLAG_STATS render (algorithmic-bytes bookkeeping,
@@ -144,6 +145,9 @@ int pt_set_bvh4(PtContext* ctx, const uint32_t* bvh4, uint64_t words);
 /* load a BVH2 buffer (data/BVH2.bin) and collapse it like buildBVH does after readback */
 int pt_set_bvh2(PtContext* ctx, const uint32_t* bvh2, uint64_t words);
 int pt_read_bvh4(PtContext* ctx, uint32_t* dst, uint64_t bytes);
+/* Build-defined extension for BASELINE config C1 (Cornell box: triangles + analytic spheres, no BVH):
+ * n spheres as (x, y, z, r) f32 quadruples, used only by PT_FLAG_BRUTE_FORCE renders. */
+int pt_set_spheres(PtContext* ctx, const float* xyzr, uint32_t num_spheres);
 int pt_scene_info(PtContext* ctx, uint32_t* num_tris, uint32_t* num_nodes2, uint32_t* num_nodes4);
 
 /* ---- the hot path ----------------------------------------------------------------- */

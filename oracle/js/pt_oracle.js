@@ -51,8 +51,10 @@ function sincos2pi(u, out) {
 
 class Oracle {
   // tris: Float32Array(9N), bvh4: Uint32Array(1+8M) in the reference layouts
-  constructor(tris, bvh4, numTris) {
-    this.tris = tris; this.bvh = bvh4; this.numTris = numTris; this.numNodes = bvh4[0];
+  // spheres (optional Float32Array(4S), x y z r) switches to the brute-force scene of config C1 (no BVH)
+  constructor(tris, bvh4, numTris, spheres) {
+    this.tris = tris; this.bvh = bvh4 || new Uint32Array([0]); this.numTris = numTris; this.numNodes = this.bvh[0];
+    this.spheres = spheres || null; this.brute = !!spheres;
     this.stack = new Uint32Array(STACK_MAX);
     this.stats = { raysClosest: 0, raysShadow: 0, nodesExamined: 0, trisTested: 0, samples: 0 };
     this.hit = { t: INF_T, tri: INVALID, nx: 0, ny: 0, nz: 0 };
@@ -76,7 +78,51 @@ class Oracle {
 
   // traverseBVH4Packet with one active lane (renderer.wgsl:210-346), incl. the re-test at pop,
   // the nearest-child swap and the silent push drop; anyhit stops at the first accepted hit
+  // BUILD-DEFINED: every triangle (reference Moller-Trumbore) then every sphere, strict t < best
+  bruteTrace(ox, oy, oz, dx, dy, dz, anyhit) {
+    const H = this.hit, T = this.tris, st = this.stats; H.t = INF_T; H.tri = INVALID;
+    for (let ti = 0; ti < this.numTris; ti++) {
+      const o = ti * 9; st.trisTested++;
+      const v0x = T[o], v0y = T[o + 1], v0z = T[o + 2];
+      const e1x = f(T[o + 3] - v0x), e1y = f(T[o + 4] - v0y), e1z = f(T[o + 5] - v0z);
+      const e2x = f(T[o + 6] - v0x), e2y = f(T[o + 7] - v0y), e2z = f(T[o + 8] - v0z);
+      const px = f(f(dy * e2z) - f(dz * e2y)), py = f(f(dz * e2x) - f(dx * e2z)), pz = f(f(dx * e2y) - f(dy * e2x));
+      const det = dot(e1x, e1y, e1z, px, py, pz);
+      if (Math.abs(det) < EPS_TRI) continue;
+      const inv = f(1 / det), sx = f(ox - v0x), sy = f(oy - v0y), sz = f(oz - v0z);
+      const u = f(inv * dot(sx, sy, sz, px, py, pz)); if (u < 0 || u > 1) continue;
+      const qx = f(f(sy * e1z) - f(sz * e1y)), qy = f(f(sz * e1x) - f(sx * e1z)), qz = f(f(sx * e1y) - f(sy * e1x));
+      const v = f(inv * dot(dx, dy, dz, qx, qy, qz)); if (v < 0 || f(u + v) > 1) continue;
+      const t = f(inv * dot(e2x, e2y, e2z, qx, qy, qz));
+      if (t > EPS_TRI && t < H.t) {
+        H.t = t; H.tri = ti;
+        const cx = f(f(e1y * e2z) - f(e1z * e2y)), cy = f(f(e1z * e2x) - f(e1x * e2z)), cz = f(f(e1x * e2y) - f(e1y * e2x));
+        const il = f(1 / f(Math.sqrt(dot(cx, cy, cz, cx, cy, cz))));
+        H.nx = f(cx * il); H.ny = f(cy * il); H.nz = f(cz * il);
+        if (anyhit) return true;
+      }
+    }
+    const S = this.spheres;
+    for (let si = 0; si * 4 < S.length; si++) {
+      const cx = S[si * 4], cy = S[si * 4 + 1], cz = S[si * 4 + 2], r = S[si * 4 + 3];
+      const ocx = f(ox - cx), ocy = f(oy - cy), ocz = f(oz - cz);
+      const a = dot(dx, dy, dz, dx, dy, dz), hb = dot(ocx, ocy, ocz, dx, dy, dz), cc = f(dot(ocx, ocy, ocz, ocx, ocy, ocz) - f(r * r));
+      const disc = f(f(hb * hb) - f(a * cc));
+      if (disc < 0) continue;
+      const sq = f(Math.sqrt(disc)), t0 = f(f(-hb - sq) / a), t1 = f(f(-hb + sq) / a), t = t0 > EPS_TRI ? t0 : t1;
+      if (t > EPS_TRI && t < H.t) {
+        H.t = t; H.tri = (0x40000000 | si) >>> 0;
+        const qx = f(f(ox + f(dx * t)) - cx), qy = f(f(oy + f(dy * t)) - cy), qz = f(f(oz + f(dz * t)) - cz);
+        const il = f(1 / f(Math.sqrt(dot(qx, qy, qz, qx, qy, qz))));
+        H.nx = f(qx * il); H.ny = f(qy * il); H.nz = f(qz * il);
+        if (anyhit) return true;
+      }
+    }
+    return H.tri !== INVALID;
+  }
+
   traverse(ox, oy, oz, dx, dy, dz, anyhit) {
+    if (this.brute) return this.bruteTrace(ox, oy, oz, dx, dy, dz, anyhit);
     const H = this.hit; H.t = INF_T; H.tri = INVALID;
     if (this.numNodes === 0 || this.numTris === 0) return false;
     const ix = Math.abs(dx) > 1e-8 ? f(1 / dx) : INF_T, iy = Math.abs(dy) > 1e-8 ? f(1 / dy) : INF_T, iz = Math.abs(dz) > 1e-8 ? f(1 / dz) : INF_T;
@@ -218,8 +264,9 @@ if (require.main === module) {
   const fs = require("fs"), a = process.argv;
   const rd = (p, T) => { const b = fs.readFileSync(p); return new T(b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength)); };
   const tris = rd(a[2], Float32Array), bvh = rd(a[3], Uint32Array), P = JSON.parse(fs.readFileSync(a[4], "utf8"));
+  const spheres = P.spheres ? new Float32Array(P.spheres) : null;
   P.focal = f(P.focal); P.aspect = f(P.aspect); P.camPos = P.camPos.map(f); P.camQuat = P.camQuat.map(f);
-  const out = new Float32Array(P.width * P.height * 4), orc = new Oracle(tris, bvh, P.numTris);
+  const out = new Float32Array(P.width * P.height * 4), orc = new Oracle(tris, bvh, P.numTris, spheres);
   const t0 = Date.now(), st = orc.render(P, out), sec = (Date.now() - t0) / 1000;
   fs.writeFileSync(a[5], Buffer.from(out.buffer));
   console.log(JSON.stringify({ seconds: sec, stats: st, node: process.version }));

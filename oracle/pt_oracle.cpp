@@ -372,6 +372,8 @@ struct Node4 { V3 mn, mx; uint32_t c[4]; uint32_t triIndex; bool isLeaf; };
 
 struct SceneView {
     const float* tris; const uint32_t* bvh; uint32_t numTris; uint32_t numNodes;
+    // BUILD-DEFINED brute-force scene (config C1: triangles + analytic spheres, no BVH)
+    const float* spheres = nullptr; uint32_t numSpheres = 0; bool brute = false;
     Node4 node(uint32_t index) const {               // getBVHNode4, renderer.wgsl:91-111
         uint32_t base = 1u + index * NODE4_STRIDE;
         uint32_t a = bvh[base], b = bvh[base + 1], c = bvh[base + 2];
@@ -502,8 +504,47 @@ HitPacket traverse_packet(const SceneView& sc, const Packet& packet, const Mask&
 
 struct Hit1 { float t; V3 normal; bool hit; uint32_t tri; };
 
+constexpr uint32_t SPHERE_FLAG = 0x40000000u;
+
+// BUILD-DEFINED (parity unpinned): closest / any hit without a BVH.  Triangles in index order with the
+// reference's Moller-Trumbore (renderer.wgsl:171-208), then spheres (x,y,z,r) in index order:
+// a = d.d, hb = oc.d, disc = hb*hb - a*(oc.oc - r*r); t = nearer root if > eps else farther; strict t < best.
+Hit1 brute_single(const SceneView& sc, V3 o, V3 d, bool anyhit, Stats* st) {
+    Hit1 h{INF_T, v3(0, 0, 0), false, INVALID};
+    const float eps = 1e-7f;
+    for (uint32_t ti = 0; ti < sc.numTris; ti++) {
+        const float* b = sc.tris + size_t(ti) * 9;
+        V3 v0 = v3(b[0], b[1], b[2]), e1 = v3(b[3], b[4], b[5]) - v0, e2 = v3(b[6], b[7], b[8]) - v0;
+        if (st) st->tris_tested++;
+        V3 pv = cross(d, e2); float det = dot(e1, pv);
+        if (std::fabs(det) < eps) continue;
+        float invDet = 1.0f / det; V3 s = o - v0;
+        float u = invDet * dot(s, pv); if (u < 0.0f || u > 1.0f) continue;
+        V3 q = cross(s, e1); float v = invDet * dot(d, q); if (v < 0.0f || (u + v) > 1.0f) continue;
+        float t = invDet * dot(e2, q);
+        if (t > eps && t < h.t) { h.t = t; h.normal = normalize(cross(e1, e2)); h.hit = true; h.tri = ti; if (anyhit) return h; }
+    }
+    for (uint32_t si = 0; si < sc.numSpheres; si++) {
+        const float* sp = sc.spheres + size_t(si) * 4;
+        V3 c = v3(sp[0], sp[1], sp[2]); float r = sp[3];
+        V3 oc = o - c;
+        float a = dot(d, d), hb = dot(oc, d), cc = dot(oc, oc) - r * r;
+        float disc = hb * hb - a * cc;
+        if (disc < 0.0f) continue;
+        float sq = std::sqrt(disc);
+        float t0 = (-hb - sq) / a, t1 = (-hb + sq) / a;
+        float t = (t0 > eps) ? t0 : t1;
+        if (t > eps && t < h.t) {
+            h.t = t; V3 p = o + d * t; h.normal = normalize(p - c); h.hit = true; h.tri = SPHERE_FLAG | si;
+            if (anyhit) return h;
+        }
+    }
+    return h;
+}
+
 // Single-ray traversal == traverse_packet with exactly one active lane (lane 0).
 Hit1 traverse_single(const SceneView& sc, V3 o, V3 d, V3 inv, bool anyhit, Stats* st) {
+    if (sc.brute) return brute_single(sc, o, d, anyhit, st);
     Packet p; Mask m;
     for (int i = 0; i < PACKET_SIZE; i++) { p.origin[i] = v3(0, 0, 0); p.dir[i] = v3(0, 0, -1); p.invdir[i] = v3(INF_T, INF_T, INF_T); m.m[i] = false; }
     p.origin[0] = o; p.dir[0] = d; p.invdir[0] = inv; m.m[0] = true;
@@ -746,6 +787,36 @@ int orc_render(const Params* Pp, const float* tris, const uint32_t* bvh4, float*
                 sum = sum + fsum; count = count + float(P.spp);
             }
             float invn = 1.0f / count;
+            o[0] = sum.x * invn; o[1] = sum.y * invn; o[2] = sum.z * invn; o[3] = 1.0f;
+        }
+    }
+    return 0;
+}
+
+// BUILD-DEFINED config C1: brute-force scene of triangles + spheres (no BVH), modes 1 and 2 only.
+int orc_render_brute(const Params* Pp, const float* tris, const float* spheres, uint32_t numSpheres, float* rgba, Stats* st) {
+    Params P = *Pp;
+    if (P.mode == 0) return 1;
+    const uint32_t one = 1;   // non-empty dummy BVH word so the shared render loop takes the traced path
+    (void)one;
+    if (st) std::memset(st, 0, sizeof(Stats));
+    SceneView sc{tris, nullptr, P.num_tris, 1u};
+    sc.spheres = spheres; sc.numSpheres = numSpheres; sc.brute = true;
+    uint32_t x1 = std::min(P.x1, P.width), y1 = std::min(P.y1, P.height);
+    uint32_t sx = P.step_x ? P.step_x : 1, sy = P.step_y ? P.step_y : 1;
+    for (uint32_t py = P.y0; py < y1; py += sy)
+    for (uint32_t px = P.x0; px < x1; px += sx) {
+        float* o = rgba + (size_t(py) * P.width + px) * 4;
+        if (P.mode == 1) {
+            V3 ro, rd, ri; primary_ray(P, float(px) + 0.5f, float(py) + 0.5f, ro, rd, ri);
+            if (st) { st->rays_closest++; st->samples++; }
+            Hit1 h = traverse_single(sc, ro, rd, ri, false, st);
+            V3 col = h.hit ? shade_ref(h.normal) : v3(0.01f, 0.01f, 0.01f);
+            o[0] = col.x; o[1] = col.y; o[2] = col.z; o[3] = 1.0f;
+        } else {
+            V3 sum = v3(0, 0, 0);
+            for (uint32_t s = 0; s < P.spp; s++) { sum = sum + path_sample(sc, P, px, py, P.frame * P.spp + s, st); if (st) st->samples++; }
+            float invn = 1.0f / (0.0f + float(P.spp));
             o[0] = sum.x * invn; o[1] = sum.y * invn; o[2] = sum.z * invn; o[3] = 1.0f;
         }
     }

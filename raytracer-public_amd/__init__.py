@@ -22,6 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libmi355pt.so")
 PT_MODE_REFERENCE_PACKET, PT_MODE_REFERENCE, PT_MODE_PATH = 0, 1, 2
 PT_FLAG_STATS = 1
 PT_FLAG_SIMPLE_KERNEL = 2
+PT_FLAG_BRUTE_FORCE = 4
 SCENE_DRAGON_CLASS, SCENE_SPONZA_CLASS = 0, 1
 
 
@@ -59,7 +60,7 @@ EXPORTS = [
     "pt_compute_bvh2_sizing", "pt_compute_bvh4_sizing", "pt_morton_sort", "pt_collapse_lbvh2_to_bvh4",
     "pt_bvh2_to_bvh4_wide", "pt_file_write_u32", "pt_file_read_u32", "pt_scene_procedural",
     "pt_set_triangles", "pt_build_bvh", "pt_build_lbvh2", "pt_read_bvh2", "pt_set_bvh4", "pt_set_bvh2",
-    "pt_read_bvh4", "pt_scene_info", "pt_render", "pt_last_render_ms", "pt_timing_begin", "pt_timing_collect", "pt_set_compact_buffer", "pt_get_stats", "pt_read_radiance",
+    "pt_read_bvh4", "pt_set_spheres", "pt_scene_info", "pt_render", "pt_last_render_ms", "pt_timing_begin", "pt_timing_collect", "pt_set_compact_buffer", "pt_get_stats", "pt_read_radiance",
     "pt_read_rgba8", "pt_read_tonemapped", "pt_tile_layout", "pt_compact_radiance", "pt_deinterleave",
 ]
 
@@ -200,6 +201,10 @@ class Context:
         self._ck(lib.pt_set_triangles(self.h, _p(tris, C.c_float), C.c_uint32(tris.size // 9)))
         self.num_tris = tris.size // 9
 
+    def set_spheres(self, xyzr):
+        xyzr = np.ascontiguousarray(xyzr, np.float32).reshape(-1)
+        self._ck(lib.pt_set_spheres(self.h, _p(xyzr, C.c_float), C.c_uint32(xyzr.size // 4)))
+
     def build_bvh(self):
         self._ck(lib.pt_build_bvh(self.h))
 
@@ -231,7 +236,7 @@ class Context:
         return out
 
     def make_params(self, width, height, cam_pos=(0, 0, 2.5), cam_quat=(0, 0, 0, 1), mode=PT_MODE_REFERENCE, spp=1,
-                    max_bounces=0, seed=1, frame=0, accumulate=False, tile_rank=0, tile_count=1, stats=False, num_tris=None, simple_kernel=False):
+                    max_bounces=0, seed=1, frame=0, accumulate=False, tile_rank=0, tile_count=1, stats=False, num_tris=None, simple_kernel=False, brute_force=False):
         p = PtRenderParams()
         p.width, p.height = width, height
         p.focal, p.aspect = focal_aspect(width, height)
@@ -241,7 +246,7 @@ class Context:
         p.frame, p.mode, p.spp, p.max_bounces, p.seed = frame, mode, spp, max_bounces, seed
         p.accumulate = 1 if accumulate else 0
         p.tile_rank, p.tile_count = tile_rank, tile_count
-        p.flags = (PT_FLAG_STATS if stats else 0) | (PT_FLAG_SIMPLE_KERNEL if simple_kernel else 0)
+        p.flags = (PT_FLAG_STATS if stats else 0) | (PT_FLAG_SIMPLE_KERNEL if simple_kernel else 0) | (PT_FLAG_BRUTE_FORCE if brute_force else 0)
         return p
 
     def render(self, params):

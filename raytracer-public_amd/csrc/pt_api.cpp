@@ -52,6 +52,7 @@ struct PtContext {
     DevBuf<uint32_t> d_bvh2, d_bvh4; // reference layouts
     DevBuf<uint4> d_wide;            // 4 x uint4 per internal node
     DevBuf<uint32_t> d_morton, d_triidx, d_parent, d_flags;
+    DevBuf<float4> d_spheres; uint32_t num_spheres = 0;
 
     // frame
     DevBuf<float4> d_out, d_accum, d_compact, d_compact_accum;
@@ -155,7 +156,7 @@ void pt_destroy(PtContext* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->d_tris9.release(); ctx->d_trirec.release(); ctx->d_bvh2.release(); ctx->d_bvh4.release(); ctx->d_wide.release();
-    ctx->d_morton.release(); ctx->d_triidx.release(); ctx->d_parent.release(); ctx->d_flags.release();
+    ctx->d_spheres.release(); ctx->d_morton.release(); ctx->d_triidx.release(); ctx->d_parent.release(); ctx->d_flags.release();
     ctx->d_out.release(); ctx->d_accum.release(); ctx->d_compact.release(); ctx->d_compact_accum.release();
     ctx->d_tiles.release(); ctx->d_u32tmp.release(); ctx->d_stats.release();
     ctx->d_wave_times.release();
@@ -372,6 +373,15 @@ int pt_read_bvh4(PtContext* ctx, uint32_t* dst, uint64_t bytes) {
     return PT_OK;
 }
 
+int pt_set_spheres(PtContext* ctx, const float* xyzr, uint32_t num_spheres) {
+    if (int rc = bind(ctx)) return rc;
+    if (num_spheres && !xyzr) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_spheres: null spheres");
+    PT_HIP(ctx, ctx->d_spheres.ensure(num_spheres));
+    if (num_spheres) PT_HIP(ctx, hipMemcpy(ctx->d_spheres.ptr, xyzr, size_t(num_spheres) * 16, hipMemcpyHostToDevice));
+    ctx->num_spheres = num_spheres; ctx->accum_count = 0;
+    return PT_OK;
+}
+
 int pt_scene_info(PtContext* ctx, uint32_t* num_tris, uint32_t* num_nodes2, uint32_t* num_nodes4) {
     if (!ctx) return fail(nullptr, PT_ERR_INVALID_ARG, "null context");
     if (num_tris) *num_tris = ctx->num_tris;
@@ -394,7 +404,9 @@ int pt_tile_layout(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t
 int pt_render(PtContext* ctx, const PtRenderParams* p) {
     if (int rc = bind(ctx)) return rc;
     if (!p) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: null params");
-    if (!ctx->have_tris || !ctx->have_bvh) return fail(ctx, PT_ERR_NO_SCENE, "pt_render: scene not set (triangles + BVH)");   // PathTracer.js:757
+    const bool brute = (p->flags & PT_FLAG_BRUTE_FORCE) != 0;
+    if (!ctx->have_tris || (!ctx->have_bvh && !brute)) return fail(ctx, PT_ERR_NO_SCENE, "pt_render: scene not set (triangles + BVH)");   // PathTracer.js:757
+    if (brute && p->mode == PT_MODE_REFERENCE_PACKET) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: brute-force scenes render in modes 1 and 2");
     if (p->width == 0 || p->height == 0 || p->width > 32768 || p->height > 32768) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: bad resolution");
     if (p->num_tris > ctx->num_tris) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: num_tris exceeds the uploaded triangle count");
     if (p->mode > PT_MODE_PATH) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: unknown mode");
@@ -413,6 +425,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     A.num_tris = p->num_tris; A.frame = p->frame;
     A.root_ref = ctx->wide_meta.root_ref; std::memcpy(A.root_box, ctx->wide_meta.root_box, 12);
     A.root_degenerate = ctx->wide_meta.root_degenerate ? 1u : 0u;
+    A.spheres = ctx->d_spheres.ptr; A.num_spheres = brute ? ctx->num_spheres : 0u; A.brute = brute ? 1u : 0u;
     A.spp = p->spp; A.max_bounces = p->max_bounces; A.seed = p->seed; A.accumulate = 0; A.compact = sharded ? 1u : 0u;
     A.tiles_x = (p->width + pt::kTile - 1) / pt::kTile;
     const uint32_t tiles_y = (p->height + pt::kTile - 1) / pt::kTile;
@@ -461,7 +474,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     const bool ring = ctx->ring_used + 2 <= ctx->ring.size();
     hipEvent_t e0 = ring ? ctx->ring[ctx->ring_used] : ctx->ev_start, e1 = ring ? ctx->ring[ctx->ring_used + 1] : ctx->ev_stop;
     const int kmode = p->mode == PT_MODE_REFERENCE_PACKET ? PT_KMODE_PACKET : (p->mode == PT_MODE_REFERENCE ? PT_KMODE_REFERENCE : PT_KMODE_PATH);
-    if (kmode == PT_KMODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL)) {
+    if (kmode == PT_KMODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute) {
         const uint32_t grid = ptk::megakernel_grid(ctx->num_cus > 0 ? ctx->num_cus : 256);
         const uint32_t grid_lanes = grid * ptk::megakernel_block();
         A.num_batches = A.num_tiles * p->spp;

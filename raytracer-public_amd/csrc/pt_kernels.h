@@ -47,6 +47,8 @@ struct RenderArgs {
     float4*   out;              // radiance: row-major W*H, or compact tile-major (64 px per owned tile)
     float4*   accum;            // running per-pixel sums (xyz) + sample count (w); nullptr in reference modes
     uint32_t* tri_ids;          // optional: closest-hit triangle of the primary ray (reference modes)
+    const float4* spheres;      // config C1 brute-force scenes: (x, y, z, r) per sphere
+    uint32_t num_spheres, brute;
     const uint32_t* tiles;      // owned tile ids, nullptr = every tile in row-major order
     unsigned long long* stats;  // 7 counters (PtStats order)
     uint32_t num_tiles, tiles_x;

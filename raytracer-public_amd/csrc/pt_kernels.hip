@@ -104,8 +104,63 @@ __device__ __forceinline__ bool traverse(const RenderArgs& A, const Ray& r, floa
     return best_tri != kInvalidRef;
 }
 
+constexpr uint32_t kSphereFlag = 0x40000000u;
+
+// BUILD-DEFINED config C1: no BVH -- every triangle record in index order with the
+// reference's Moller-Trumbore, then every analytic sphere (x,y,z,r) in index order; strict t < best.
+template <bool ANYHIT, bool STATS>
+__device__ __forceinline__ bool brute_trace(const RenderArgs& A, const Ray& r, float& best_t, uint32_t& best_prim, Counters& cnt) {
+    best_t = kInfT; best_prim = kInvalidRef;
+    for (uint32_t ti = 0; ti < A.num_tris; ++ti) {
+        const float4* tp = A.tris + (size_t)ti * 3;
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        if (STATS) cnt.tris += 1;
+        const F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
+        const F3 p = cross3(r.d, e2);
+        const float det = dot3(e1, p);
+        if (fabsf(det) < kTriEps) continue;
+        const float inv_det = 1.0f / det;
+        const F3 s = r.o - v0;
+        const float u = inv_det * dot3(s, p);
+        if (u < 0.0f || u > 1.0f) continue;
+        const F3 q = cross3(s, e1);
+        const float v = inv_det * dot3(r.d, q);
+        if (v < 0.0f || (u + v) > 1.0f) continue;
+        const float t = inv_det * dot3(e2, q);
+        if (t > kTriEps && t < best_t) { best_t = t; best_prim = ti; if (ANYHIT) return true; }
+    }
+    for (uint32_t si = 0; si < A.num_spheres; ++si) {
+        const float4 sp = A.spheres[si];
+        const F3 oc = r.o - f3(sp.x, sp.y, sp.z);
+        const float a = dot3(r.d, r.d), hb = dot3(oc, r.d), cc = dot3(oc, oc) - sp.w * sp.w;
+        const float disc = hb * hb - a * cc;
+        if (disc < 0.0f) continue;
+        const float sq = sqrtf(disc);
+        const float t0 = (-hb - sq) / a, t1 = (-hb + sq) / a;
+        const float t = (t0 > kTriEps) ? t0 : t1;
+        if (t > kTriEps && t < best_t) { best_t = t; best_prim = kSphereFlag | si; if (ANYHIT) return true; }
+    }
+    return best_prim != kInvalidRef;
+}
+
+template <bool ANYHIT, bool STATS, bool BRUTE>
+__device__ __forceinline__ bool trace_any(const RenderArgs& A, const Ray& r, float& t, uint32_t& prim, uint2* stk, Counters& cnt) {
+    if (BRUTE) return brute_trace<ANYHIT, STATS>(A, r, t, prim, cnt);
+    return traverse<ANYHIT, STATS>(A, r, t, prim, stk, cnt);
+}
+
+template <bool BRUTE>
+__device__ __forceinline__ F3 hit_normal(const RenderArgs& A, uint32_t prim, const Ray& r, float t) {
+    if (BRUTE && (prim & kSphereFlag)) {
+        const float4 sp = A.spheres[prim & ~kSphereFlag];
+        const F3 p = r.o + r.d * t;
+        return normalize3(p - f3(sp.x, sp.y, sp.z));
+    }
+    return tri_normal(A, prim);
+}
+
 // One work item = one pixel.  A wavefront owns one 8x8 tile (lane = y*8+x inside the tile).
-template <int MODE, bool STATS>
+template <int MODE, bool STATS, bool BRUTE>
 __global__ __launch_bounds__(256) void render_rays_kernel(const RenderArgs A) {
     const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t slot = item >> 6, lane = item & 63u;
@@ -126,10 +181,10 @@ __global__ __launch_bounds__(256) void render_rays_kernel(const RenderArgs A) {
         const Ray r = primary_ray(A, (float)px + 0.5f, (float)py + 0.5f);
         float t; uint32_t tri;
         n_closest = 1;
-        const bool hit = traverse<false, STATS>(A, r, t, tri, stk, cnt);
+        const bool hit = trace_any<false, STATS, BRUTE>(A, r, t, tri, stk, cnt);
         F3 col = f3(0.01f, 0.01f, 0.01f);
         if (hit) {                                           // shade(), renderer.wgsl:348-353
-            const float ndotl = wmax(dot3(tri_normal(A, tri), L), 0.0f);
+            const float ndotl = wmax(dot3(hit_normal<BRUTE>(A, tri, r, t), L), 0.0f);
             col = base * (0.15f + ndotl);
         }
         A.out[out_index] = make_float4(col.x, col.y, col.z, 1.0f);
@@ -144,9 +199,9 @@ __global__ __launch_bounds__(256) void render_rays_kernel(const RenderArgs A) {
             for (uint32_t bounce = 0;; ++bounce) {
                 float t; uint32_t tri;
                 ++n_closest;
-                const bool hit = traverse<false, STATS>(A, r, t, tri, stk, cnt);
+                const bool hit = trace_any<false, STATS, BRUTE>(A, r, t, tri, stk, cnt);
                 if (!hit) { rad = rad + T * ((bounce == 0u) ? kBgPrimary : kSkyAmbient); break; }
-                const F3 n = tri_normal(A, tri);
+                const F3 n = hit_normal<BRUTE>(A, tri, r, t);
                 const F3 hp = r.o + r.d * t;
                 const F3 nf = (dot3(n, r.d) < 0.0f) ? n : f3(-n.x, -n.y, -n.z);
                 const F3 so = hp + nf * kEpsOrigin;
@@ -155,7 +210,7 @@ __global__ __launch_bounds__(256) void render_rays_kernel(const RenderArgs A) {
                     Ray sr; sr.o = so; sr.d = L; sr.inv = safe_inv(L);
                     float st; uint32_t stri;
                     ++n_shadow;
-                    if (!traverse<true, STATS>(A, sr, st, stri, stk, cnt)) rad = rad + (T * base) * ndl;
+                    if (!trace_any<true, STATS, BRUTE>(A, sr, st, stri, stk, cnt)) rad = rad + (T * base) * ndl;
                 }
                 if (bounce >= A.max_bounces) break;
                 T = T * base;
@@ -463,13 +518,16 @@ hipError_t launch_render(const RenderArgs& A, int kmode, bool stats, hipStream_t
     const uint32_t items = A.num_tiles * 64u;
     const dim3 grid((items + 255u) / 256u), block(256);
     if (grid.x == 0) return hipSuccess;
+    const bool brute = A.brute != 0u;
+#define PT_LAUNCH(M, S, B) hipLaunchKernelGGL((render_rays_kernel<M, S, B>), grid, block, 0, stream, A)
     if (kmode == PT_KMODE_REFERENCE) {
-        if (stats) hipLaunchKernelGGL((render_rays_kernel<PT_KMODE_REFERENCE, true>), grid, block, 0, stream, A);
-        else       hipLaunchKernelGGL((render_rays_kernel<PT_KMODE_REFERENCE, false>), grid, block, 0, stream, A);
+        if (brute) { if (stats) PT_LAUNCH(PT_KMODE_REFERENCE, true, true); else PT_LAUNCH(PT_KMODE_REFERENCE, false, true); }
+        else       { if (stats) PT_LAUNCH(PT_KMODE_REFERENCE, true, false); else PT_LAUNCH(PT_KMODE_REFERENCE, false, false); }
     } else {
-        if (stats) hipLaunchKernelGGL((render_rays_kernel<PT_KMODE_PATH, true>), grid, block, 0, stream, A);
-        else       hipLaunchKernelGGL((render_rays_kernel<PT_KMODE_PATH, false>), grid, block, 0, stream, A);
+        if (brute) { if (stats) PT_LAUNCH(PT_KMODE_PATH, true, true); else PT_LAUNCH(PT_KMODE_PATH, false, true); }
+        else       { if (stats) PT_LAUNCH(PT_KMODE_PATH, true, false); else PT_LAUNCH(PT_KMODE_PATH, false, false); }
     }
+#undef PT_LAUNCH
     return hipGetLastError();
 }
 

@@ -34,7 +34,7 @@ class PathTracer {
       device: o.device === undefined ? -1 : o.device,
       mode: o.mode === undefined ? MODE_REFERENCE : o.mode,
       spp: o.spp || 1, maxBounces: o.maxBounces || 0, seed: o.seed === undefined ? 1 : o.seed,
-      accumulate: !!o.accumulate, stats: !!o.stats,
+      accumulate: !!o.accumulate, stats: !!o.stats, bruteForce: !!o.bruteForce,
     };
     this._hasBVH = false;
   }
@@ -71,6 +71,14 @@ class PathTracer {
   async setScene(scene) {                        // :751-754
     this.trianglesData = scene.getTrianglesFloat32();
     await this.buildBVH(this.trianglesData);
+  }
+
+  // config C1 extension: brute-force scene = uploaded triangles + analytic spheres, no BVH
+  setBruteForceScene(trianglesData, spheresXYZR) {
+    this.trianglesData = trianglesData;
+    native().setTriangles(this.device, trianglesData);
+    native().setSpheres(this.device, spheresXYZR);
+    this.options.bruteForce = true; this._hasBVH = true;
   }
 
   // install a prebuilt BVH (data/BVH2.bin or data/BVH4_wide.bin) instead of rebuilding

@@ -250,6 +250,13 @@ static napi_value fn_set_bvh2(napi_env env, napi_callback_info info) {
     PT_CALL(ctx, pt_set_bvh2(ctx, (const uint32_t*)d, len), "pt_set_bvh2");
     return NULL;
 }
+static napi_value fn_set_spheres(napi_env env, napi_callback_info info) {     /* config C1 extension: (x,y,z,r) per sphere */
+    napi_value argv[2]; if (!get_args(env, info, 2, argv)) return NULL;
+    PtContext* ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    void* d; size_t len; if (!get_typed(env, argv[1], napi_float32_array, &d, &len)) return NULL;
+    PT_CALL(ctx, pt_set_spheres(ctx, (const float*)d, (uint32_t)(len / 4)), "pt_set_spheres");
+    return NULL;
+}
 static napi_value fn_scene_info(napi_env env, napi_callback_info info) {
     napi_value argv[1]; if (!get_args(env, info, 1, argv)) return NULL;
     PtContext* ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
@@ -283,7 +290,8 @@ static napi_value fn_render(napi_env env, napi_callback_info info) {          /*
     p.accumulate = prop_u32(env, opt, "accumulate", 0);
     p.tile_rank = prop_u32(env, opt, "tileRank", 0);
     p.tile_count = prop_u32(env, opt, "tileCount", 1);
-    p.flags = (prop_u32(env, opt, "stats", 0) ? PT_FLAG_STATS : 0u) | (prop_u32(env, opt, "simpleKernel", 0) ? PT_FLAG_SIMPLE_KERNEL : 0u);
+    p.flags = (prop_u32(env, opt, "stats", 0) ? PT_FLAG_STATS : 0u) | (prop_u32(env, opt, "simpleKernel", 0) ? PT_FLAG_SIMPLE_KERNEL : 0u) |
+              (prop_u32(env, opt, "bruteForce", 0) ? PT_FLAG_BRUTE_FORCE : 0u);
     (void)prop_f64;
     PT_CALL(ctx, pt_render(ctx, &p), "pt_render");
     return NULL;
@@ -339,7 +347,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"mortonSort", fn_morton_sort}, {"collapse", fn_collapse}, {"bvh4Wide", fn_bvh4_wide},
         {"writeU32File", fn_write_u32}, {"readU32File", fn_read_u32}, {"proceduralScene", fn_procedural},
         {"setTriangles", fn_set_triangles}, {"buildBVH", fn_build_bvh}, {"readBVH2", fn_read_bvh2}, {"readBVH4", fn_read_bvh4},
-        {"setBVH4", fn_set_bvh4}, {"setBVH2", fn_set_bvh2}, {"sceneInfo", fn_scene_info},
+        {"setBVH4", fn_set_bvh4}, {"setBVH2", fn_set_bvh2}, {"setSpheres", fn_set_spheres}, {"sceneInfo", fn_scene_info},
         {"render", fn_render}, {"lastRenderMs", fn_last_ms}, {"synchronize", fn_sync}, {"getStats", fn_stats},
         {"readRadiance", fn_read_radiance}, {"readRGBA8", fn_read_rgba8}, {"readTonemapped", fn_read_tonemapped},
     };

@@ -128,6 +128,15 @@ class Oracle:
         assert rc == 0
         return img, ids, st.as_dict()
 
+    def render_brute(self, params, tris, spheres):
+        tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1)
+        spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1)
+        img = np.zeros((params.height, params.width, 4), np.float32)
+        st = Stats()
+        rc = self.lib.orc_render_brute(C.byref(params), _p(tris, C.c_float), _p(spheres, C.c_float), C.c_uint32(spheres.size // 4), _p(img, C.c_float), C.byref(st))
+        assert rc == 0
+        return img, st.as_dict()
+
     def trace_ray(self, tris, bvh4, o, d, anyhit=False):
         tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1)
         bvh4 = np.ascontiguousarray(bvh4, dtype=np.uint32)

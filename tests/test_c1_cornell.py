@@ -1,0 +1,53 @@
+"""BASELINE config C1: Cornell-class box (10 triangles + 2 spheres, no BVH), 256x256, 1 spp, 2 bounces.
+The Node/CPU path (oracle/js/pt_oracle.js) is the reference run; the C++ oracle and the HIP brute-force
+kernel must reproduce it bit for bit."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc as orc_mod
+from scenes import cornell
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+NODE = shutil.which("node")
+W = H = 256
+
+
+def node_cpu_render(tmp_path, tris, spheres, mode, spp, bounces, seed):
+    focal, aspect = orc_mod.focal_aspect(W, H)
+    tris.tofile(str(tmp_path / "t")); np.array([0], np.uint32).tofile(str(tmp_path / "b"))
+    P = dict(width=W, height=H, focal=float(focal), aspect=float(aspect), camPos=[0, 0, 2.5], camQuat=[0, 0, 0, 1], frame=0, mode=mode,
+             spp=spp, maxBounces=bounces, seed=seed, numTris=10, spheres=[float(x) for x in spheres])
+    (tmp_path / "p").write_text(json.dumps(P))
+    info = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "oracle", "js", "pt_oracle.js"), str(tmp_path / "t"), str(tmp_path / "b"), str(tmp_path / "p"), str(tmp_path / "o")], text=True))
+    return np.fromfile(str(tmp_path / "o"), np.float32).reshape(H, W, 4), info
+
+
+@pytest.mark.skipif(NODE is None, reason="node missing")
+def test_c1_node_cpu_path_equals_cpp_oracle(orc, tmp_path):
+    tris, spheres = cornell()
+    img, info = node_cpu_render(tmp_path, tris, spheres, 2, 1, 2, 1)
+    ref, st = orc.render_brute(orc.make_params(W, H, 10, mode=orc_mod.MODE_PATH, spp=1, max_bounces=2, seed=1), tris, spheres)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert info["stats"]["samples"] == W * H == st["samples"] and info["stats"]["raysClosest"] == st["rays_closest"]
+    # the picture is a lit box with two spheres: most camera rays hit, both spheres are visible
+    assert (ref[..., 0] > 0.011).mean() > 0.4
+    assert 0.05 < ref[..., :3].mean() < 0.8
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node missing")
+def test_c1_hip_brute_force_equals_node_cpu_path(rt, orc, gpu_ctx, tmp_path):
+    tris, spheres = cornell()
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.set_spheres(spheres)
+    for mode, jmode, spp, bounces in ((rt.PT_MODE_PATH, 2, 1, 2), (rt.PT_MODE_PATH, 2, 3, 4), (rt.PT_MODE_REFERENCE, 1, 1, 0)):
+        gpu_ctx.render(gpu_ctx.make_params(W, H, mode=mode, spp=spp, max_bounces=bounces, seed=1, brute_force=True))
+        got = gpu_ctx.read_radiance()
+        img, _ = node_cpu_render(tmp_path, tris, spheres, jmode, spp, bounces, 1)
+        assert np.array_equal(got.view(np.uint32), img.view(np.uint32)), (mode, spp, bounces)
