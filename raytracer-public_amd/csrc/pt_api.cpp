@@ -64,7 +64,7 @@ struct PtContext {
         hipStream_t side = nullptr; hipEvent_t resolved = nullptr, done = nullptr; bool used = false;
         DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<float4> cont;
     };
-    static constexpr int kMaxSlots = 8;
+    static constexpr int kMaxSlots = 16;
     FrameSlot slots[kMaxSlots]; int num_slots = 0; uint32_t next_slot = 0;
     DevBuf<unsigned long long> d_wave_times; uint32_t wave_times_n = 0;
     int num_cus = 0;
@@ -475,7 +475,8 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     hipEvent_t e0 = ring ? ctx->ring[ctx->ring_used] : ctx->ev_start, e1 = ring ? ctx->ring[ctx->ring_used + 1] : ctx->ev_stop;
     const int kmode = p->mode == PT_MODE_REFERENCE_PACKET ? PT_KMODE_PACKET : (p->mode == PT_MODE_REFERENCE ? PT_KMODE_REFERENCE : PT_KMODE_PATH);
     if (kmode == PT_KMODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute) {
-        const uint32_t grid = ptk::megakernel_grid(ctx->num_cus > 0 ? ctx->num_cus : 256);
+        uint32_t grid = ptk::megakernel_grid(ctx->num_cus > 0 ? ctx->num_cus : 256);
+        { const uint32_t div = tune("PT_TUNE_GRIDDIV", 1u); if (div > 1u) grid = (grid + div - 1u) / div; }
         const uint32_t grid_lanes = grid * ptk::megakernel_block();
         A.num_batches = A.num_tiles * p->spp;
         A.perm_cols = (A.num_batches + 63u) / 64u;
