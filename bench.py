@@ -24,7 +24,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime initialises (overlapped frame slots)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")   # before the HIP runtime initialises (overlapped frame slots)
 
 WIDTH, HEIGHT, SPP, BOUNCES, SEED = 1920, 1080, 4, 8, 1
 NUM_TRIS, SCENE_SEED = 871414, 20260109

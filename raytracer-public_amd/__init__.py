@@ -68,7 +68,7 @@ EXPORTS = [
 def _load():
     # the trace phases of consecutive frames overlap on side streams; ROCm's default of 4 hardware
     # queues would serialise them (read by the HIP runtime when it initialises)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "libmi355pt.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -62,7 +62,7 @@ struct PtContext {
     // dense start of the next; the resolve passes stay in call order on the main stream.
     struct FrameSlot {
         hipStream_t side = nullptr; hipEvent_t resolved = nullptr, done = nullptr; bool used = false;
-        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<float4> cont;
+        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<float4> cont; DevBuf<uint32_t> flags;
     };
     static constexpr int kMaxSlots = 16;
     FrameSlot slots[kMaxSlots]; int num_slots = 0; uint32_t next_slot = 0;
@@ -161,7 +161,7 @@ void pt_destroy(PtContext* ctx) {
     ctx->d_tiles.release(); ctx->d_u32tmp.release(); ctx->d_stats.release();
     ctx->d_wave_times.release();
     for (auto& sl : ctx->slots) {
-        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.cont.release();
+        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.cont.release(); sl.flags.release();
         if (sl.resolved) (void)hipEventDestroy(sl.resolved);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.side) { (void)hipStreamSynchronize(sl.side); (void)hipStreamDestroy(sl.side); }
@@ -476,14 +476,15 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     const int kmode = p->mode == PT_MODE_REFERENCE_PACKET ? PT_KMODE_PACKET : (p->mode == PT_MODE_REFERENCE ? PT_KMODE_REFERENCE : PT_KMODE_PATH);
     if (kmode == PT_KMODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute) {
         uint32_t grid = ptk::megakernel_grid(ctx->num_cus > 0 ? ctx->num_cus : 256);
-        { const uint32_t div = tune("PT_TUNE_GRIDDIV", 1u); if (div > 1u) grid = (grid + div - 1u) / div; }
+        // a tile-sharded frame is a fraction of the work: fewer, denser wavefronts (measured: 1/8 frame best at grid/4)
+        { const uint32_t div = tune("PT_TUNE_GRIDDIV", count >= 8u ? 4u : (count >= 2u ? 2u : 1u)); if (div > 1u) grid = (grid + div - 1u) / div; }
         const uint32_t grid_lanes = grid * ptk::megakernel_block();
         A.num_batches = A.num_tiles * p->spp;
         A.perm_cols = (A.num_batches + 63u) / 64u;
         A.total_items = A.perm_cols * 64u * 64u;
         A.chunk_items = tune("PT_TUNE_CHUNK", 512u);
         A.shade_threshold = tune("PT_TUNE_SHADE", PT_SHADE_THRESHOLD); A.fill_threshold = tune("PT_TUNE_FILL", PT_FILL_THRESHOLD);
-        A.flush_threshold = tune("PT_TUNE_FLUSH", PT_FLUSH_THRESHOLD); A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES); A.drop_cont = tune("PT_TUNE_DROPCONT", 0u);
+        A.flush_threshold = tune("PT_TUNE_FLUSH", sharded ? 0u : PT_FLUSH_THRESHOLD);   // sharded frames are too small to profit from a second pass A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES); A.drop_cont = tune("PT_TUNE_DROPCONT", 0u); A.adopt = tune("PT_TUNE_ADOPT", 0u);
         // frame slot (instrumented launches always use slot 0 and are not overlapped)
         int want_slots = int(tune("PT_TUNE_SLOTS", PT_FRAME_SLOTS));
         if (want_slots < 1) want_slots = 1;
@@ -498,9 +499,10 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         PT_HIP(ctx, sl.queue.ensure(16));
         PT_HIP(ctx, sl.samples.ensure(size_t(A.num_batches) * 64u));
         PT_HIP(ctx, sl.spill.ensure(size_t(grid_lanes) * size_t(64 - PT_SHORT_STACK)));
-        A.cont_capacity = grid_lanes;
-        PT_HIP(ctx, sl.cont.ensure(A.cont_passes ? size_t(A.cont_capacity) * 4u * 2u : 4u));
-        A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.cont_out = sl.cont.ptr;
+        A.pool_capacity = grid_lanes * 2u;           // donations can repeat; a full pool just stops donating
+        PT_HIP(ctx, sl.cont.ensure(A.cont_passes ? size_t(A.pool_capacity) * 4u * 2u : 4u));
+        PT_HIP(ctx, sl.flags.ensure(A.cont_passes ? size_t(A.pool_capacity) * 2u : 4u));
+        A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr;
         if (stats) {
             const uint32_t waves = grid_lanes / 64u;
             PT_HIP(ctx, ctx->d_wave_times.ensure(size_t(waves) * 16u));

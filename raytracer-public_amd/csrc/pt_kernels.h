@@ -15,7 +15,7 @@
 #define PT_MEGA_WAVES_PER_SIMD 6   // resident 256-thread blocks per CU = waves per SIMD
 #endif
 #ifndef PT_FRAME_SLOTS
-#define PT_FRAME_SLOTS 6            // frames whose trace phases may be in flight at once (side streams)
+#define PT_FRAME_SLOTS 8            // frames whose trace phases may be in flight at once (side streams)
 #endif
 #ifndef PT_MEGA_BLOCK
 #define PT_MEGA_BLOCK 64           // threads per workgroup of the persistent kernel: single-wave groups free their CU slot as soon as the wave drains
@@ -24,10 +24,10 @@
 #define PT_SHADE_THRESHOLD 8       // shade when this many lanes of a wavefront wait with a finished ray
 #endif
 #ifndef PT_FLUSH_THRESHOLD
-#define PT_FLUSH_THRESHOLD 32      // once the queue is dry, a wavefront with fewer live lanes hands its paths to the next pass
+#define PT_FLUSH_THRESHOLD 24      // once the queue is dry, a wavefront with fewer live lanes hands its paths to the next pass
 #endif
 #ifndef PT_MAX_CONT_PASSES
-#define PT_MAX_CONT_PASSES 0       // continuation passes after pass 0 (the last one runs every path to its end)
+#define PT_MAX_CONT_PASSES 1       // continuation passes after pass 0 (the last one runs every path to its end)
 #endif
 #ifndef PT_FILL_THRESHOLD
 #define PT_FILL_THRESHOLD 8        // regenerate when this many lanes of a wavefront are without a path
@@ -68,11 +68,13 @@ struct RenderArgs {
     unsigned long long* wave_times;   // STATS diagnostics: 8 words per wave (begin, queue-empty, end ticks @100 MHz, loop counts)
     uint32_t  total_items, chunk_items;   // logical items (64*64*perm_cols) and items per queue claim
     uint32_t  num_batches, perm_cols;     // real (tile,sample) batches; columns of the 64-row batch transpose
-    // continuation records (64 B: o, d, T, rad, key, item, bounce) handed from pass to pass
-    float4*   cont_out; uint32_t* cont_out_count;
-    const float4* cont_in; const uint32_t* cont_in_count;
-    uint32_t  cont_capacity, flush_threshold, cont_passes;
+    // path pool: 64 B records (o, d, T, rad, key, item, bounce) donated by sparse wavefronts and adopted by
+    // dense / empty ones within the launch; what is left over is the input of the next pass
+    float4*   pool; uint32_t* pool_flags; uint32_t* pool_ctrl;      // ctrl: [0] reserved tail, [1] claimed head
+    const float4* in_pool; const uint32_t* in_ctrl;                  // previous pass's pool (continuation passes)
+    uint32_t  pool_capacity, flush_threshold, cont_passes;
     uint32_t  shade_threshold, fill_threshold;
+    uint32_t  adopt;            // 1: dense / empty wavefronts adopt donated paths within the launch; 0: donations wait for the next pass
     uint32_t  drop_cont;        // timing experiments only: discard flushed paths (wrong image)
 };
 

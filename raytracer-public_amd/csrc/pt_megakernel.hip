@@ -25,7 +25,7 @@
 namespace ptk {
 
 constexpr int kShort = PT_SHORT_STACK;    // LDS entries per lane
-constexpr uint32_t kPhaseIdle = 0, kPhaseTrav = 1, kPhaseDone = 2;
+constexpr uint32_t kPhaseIdle = 0, kPhaseTrav = 1, kPhaseDone = 2, kPhaseParked = 3;   // parked: waiting at a closest-ray boundary to be donated
 
 struct Lane {
     // ray
@@ -59,10 +59,19 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
     unsigned long long t_begin = 0, t_qempty = 0;
     uint32_t n_iter = 0, n_shade = 0, n_fill = 0, n_iter_q = 0; unsigned long long cy_shade = 0, cy_fill = 0, cy_step = 0, cy_step_q = 0, cy_mark = 0; unsigned long long lanes_sum = 0, lanes_sum_q = 0, leaf_lanes = 0; uint32_t spill_ops = 0, push_ops = 0, push8_ops = 0, push12_ops = 0;
     if (STATS) t_begin = wall_clock64();
-    const uint32_t total_items = CONT ? min(*A.cont_in_count, A.cont_capacity) : A.total_items;
+    // CONT passes consume what the previous pass left in its path pool: records [head, min(tail, capacity))
+    uint32_t in_base = 0, in_count = 0;
+    if (CONT) {
+        const uint32_t tail = min(A.in_ctrl[0], A.pool_capacity), head = A.in_ctrl[1];
+        in_base = head; in_count = tail > head ? tail - head : 0u;
+    }
+    const uint32_t total_items = CONT ? in_count : A.total_items;
+    const bool pool_on = A.flush_threshold != 0u;     // wave-uniform: this pass donates / adopts through A.pool
     const uint32_t chunk_items = CONT ? 64u : A.chunk_items;
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: this wave's private item range
     bool queue_empty = false;                 // wave-uniform
+    bool donated = false;                     // wave-uniform: this wavefront handed its paths over and is leaving
+    uint32_t loop_count = 0;
 
     Lane S;
     uint32_t phase = kPhaseIdle;
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                 if (STATS) { ++n_shade; cy_mark = __builtin_amdgcn_s_memtime(); }
                 // sparse wavefront and nothing left to regenerate from: hand the surviving paths to the
                 // next pass (at a closest-ray boundary) instead of finishing them at low lane utilisation
-                const bool flush_now = queue_empty && (uint32_t)__popcll(m_done | m_trav) < A.flush_threshold;
+                const bool flush_now = pool_on && queue_empty && (uint32_t)__popcll(__ballot(phase != kPhaseIdle)) < A.flush_threshold;
                 bool do_flush = false;
                 if (phase == kPhaseDone) {
                     const bool hit = S.best_tri != kInvalidRef;
@@ -149,24 +158,38 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                         phase = kPhaseIdle;
                     }
                 }
-                const unsigned long long m_flush = __ballot(do_flush);
-                if (m_flush != 0ull) {
-                    uint32_t base_idx = 0;
-                    if (lane == (uint32_t)__builtin_ctzll(m_flush)) base_idx = atomicAdd(A.cont_out_count, (uint32_t)__popcll(m_flush));
-                    base_idx = __shfl(base_idx, __builtin_ctzll(m_flush));
-                    if (do_flush) {
-                        const uint32_t idx = base_idx + (uint32_t)__popcll(m_flush & ((1ull << lane) - 1ull));
-                        if (idx < A.cont_capacity) {   // capacity = grid lanes, cannot overflow (<= 64 flushes per wave and pass)
-                            float4* rec = A.cont_out + (size_t)idx * 4;
-                            rec[0] = make_float4(S.o.x, S.o.y, S.o.z, S.d.x);
-                            rec[1] = make_float4(S.d.y, S.d.z, S.T.x, S.T.y);
-                            rec[2] = make_float4(S.T.z, S.rad.x, S.rad.y, S.rad.z);
-                            rec[3] = make_float4(__uint_as_float(S.key), __uint_as_float(S.item), __uint_as_float(S.bounce), 0.0f);
-                        }
-                        phase = kPhaseIdle;
-                    }
-                }
+                if (do_flush) phase = kPhaseParked;            // wait for the rest of the wavefront to reach a ray boundary
                 if (STATS) cy_shade += __builtin_amdgcn_s_memtime() - cy_mark;
+            }
+        }
+        // ------------------------------------------------------------------ donate parked paths (once per wavefront)
+        {
+            const unsigned long long m_park = __ballot(phase == kPhaseParked);
+            if (m_park != 0ull && __ballot(phase == kPhaseTrav || phase == kPhaseDone) == 0ull) {
+                // every live lane is parked: publish them in one event (records, release fence, flags) and leave
+                const bool parked = phase == kPhaseParked;
+                uint32_t base_idx = 0;
+                if (lane == 0) base_idx = atomicAdd(&A.pool_ctrl[0], (uint32_t)__popcll(m_park));   // reserve
+                base_idx = __builtin_amdgcn_readfirstlane(base_idx);
+                const uint32_t idx = base_idx + (uint32_t)__popcll(m_park & ((1ull << lane) - 1ull));
+                const bool stored = parked && idx < A.pool_capacity;
+                if (stored) {
+                    // write-through (sc1) stores: the record reaches memory without an L2 write-back fence
+                    uint32_t* rec = (uint32_t*)(A.pool + (size_t)idx * 4);
+                    const uint32_t w[15] = {__float_as_uint(S.o.x), __float_as_uint(S.o.y), __float_as_uint(S.o.z), __float_as_uint(S.d.x),
+                                            __float_as_uint(S.d.y), __float_as_uint(S.d.z), __float_as_uint(S.T.x), __float_as_uint(S.T.y),
+                                            __float_as_uint(S.T.z), __float_as_uint(S.rad.x), __float_as_uint(S.rad.y), __float_as_uint(S.rad.z),
+                                            S.key, S.item, S.bounce};
+#pragma unroll
+                    for (int k = 0; k < 15; ++k) __hip_atomic_store(rec + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    phase = kPhaseIdle;
+                } else if (parked) {                             // pool full: the path simply continues here
+                    if (STATS) ++c_closest;
+                    phase = begin_ray() ? kPhaseTrav : kPhaseDone;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every record store has left before its flag is set
+                if (stored) __hip_atomic_store(&A.pool_flags[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                donated = true;
             }
         }
         // ------------------------------------------------------------------ refill IDLE lanes
@@ -189,7 +212,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                     const uint32_t avail = chunk_end - chunk_next;
                     if (phase == kPhaseIdle && rank < avail) {
                         if (CONT) {
-                            const float4* rec = A.cont_in + (size_t)(chunk_next + rank) * 4;
+                            const float4* rec = A.in_pool + (size_t)(in_base + chunk_next + rank) * 4;
                             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                             S.o = f3(r0.x, r0.y, r0.z); S.d = f3(r0.w, r1.x, r1.y); S.inv = safe_inv(S.d);
                             S.T = f3(r1.z, r1.w, r2.x); S.rad = f3(r2.y, r2.z, r2.w);
@@ -228,11 +251,60 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                 if (STATS) cy_fill += __builtin_amdgcn_s_memtime() - cy_mark;
             }
         }
+        // ------------------------------------------------------------------ adopt donated paths
+        // Once the item queue is dry, a wavefront that is empty or still dense fills its idle lanes from
+        // the pool; a sparse one (0 < live < flush_threshold) is a donor and does not adopt.
+        bool pool_drained = true;
+        ++loop_count;
+        if (pool_on && A.adopt != 0u && queue_empty && !donated && ((loop_count & 15u) == 0u || __ballot(phase == kPhaseTrav) == 0ull)) {
+            const unsigned long long m_idle = __ballot(phase == kPhaseIdle);
+            const uint32_t live = 64u - (uint32_t)__popcll(m_idle);
+            const unsigned long long m_trav2 = __ballot(phase == kPhaseTrav);
+            const bool donor = live != 0u && live < A.flush_threshold;
+            if (!donor && ((uint32_t)__popcll(m_idle) >= 16u || m_trav2 == 0ull)) {
+                const uint32_t want = (uint32_t)__popcll(m_idle);
+                uint32_t start = 0, take = 0;
+                if (lane == 0) {
+                    for (int attempt = 0; attempt < 4 && take == 0u; ++attempt) {
+                        const uint32_t tail = min(__hip_atomic_load(&A.pool_ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), A.pool_capacity);
+                        const uint32_t head = __hip_atomic_load(&A.pool_ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (tail <= head) break;
+                        if (live == 0u && tail - head < 32u) break;      // an empty wavefront only starts over with a dense batch
+                        const uint32_t n = min(tail - head, want);
+                        if (atomicCAS(&A.pool_ctrl[1], head, head + n) == head) { start = head; take = n; }
+                    }
+                }
+                start = __builtin_amdgcn_readfirstlane(start); take = __builtin_amdgcn_readfirstlane(take);
+                if (take != 0u) {
+                    pool_drained = false;
+                    const uint32_t rank = (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull));
+                    const bool mine = phase == kPhaseIdle && rank < take;
+                    const uint32_t idx = start + (mine ? rank : 0u);
+                    // the slot is reserved, its donor publishes the flag right after writing: bounded wait
+                    uint32_t spins = 0;
+                    while (mine && __hip_atomic_load(&A.pool_flags[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && spins < (1u << 22)) { __builtin_amdgcn_s_sleep(2); ++spins; }
+                    if (mine) {
+                        // sc1 loads (they bypass this CU's L1), issued only after the lane's own flag poll matched
+                        const uint32_t* rec = (const uint32_t*)(A.pool + (size_t)idx * 4);
+                        uint32_t w[15];
+#pragma unroll
+                        for (int k = 0; k < 15; ++k) w[k] = __hip_atomic_load(rec + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        S.o = f3(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]));
+                        S.d = f3(__uint_as_float(w[3]), __uint_as_float(w[4]), __uint_as_float(w[5])); S.inv = safe_inv(S.d);
+                        S.T = f3(__uint_as_float(w[6]), __uint_as_float(w[7]), __uint_as_float(w[8]));
+                        S.rad = f3(__uint_as_float(w[9]), __uint_as_float(w[10]), __uint_as_float(w[11]));
+                        S.key = w[12]; S.item = w[13]; S.bounce = w[14];
+                        if (STATS) ++c_closest;
+                        phase = begin_ray() ? kPhaseTrav : kPhaseDone;
+                    }
+                }
+            } else if (donor) pool_drained = false;
+        }
         // ------------------------------------------------------------------ exit / idle-spin
         const unsigned long long m_trav = __ballot(phase == kPhaseTrav);
         if (m_trav == 0ull) {
             const unsigned long long m_done = __ballot(phase == kPhaseDone);
-            if (m_done == 0ull && queue_empty) break;
+            if (m_done == 0ull && queue_empty && pool_drained) break;   // leftovers in the pool go to the next pass
             continue;
         }
         // ------------------------------------------------------------------ one traversal step
@@ -406,24 +478,33 @@ hipError_t launch_trace(const RenderArgs& A0, bool stats, uint32_t grid_blocks, 
     const uint32_t n_samples = A.num_batches * 64u;
     hipLaunchKernelGGL(prefill_samples_kernel, dim3(2048), dim3(256), 0, stream, A.samples, n_samples);
     e = hipGetLastError(); if (e != hipSuccess) return e;
+    // control block (u32): [0..3] item cursors of the passes; [4],[5] tail/head of pool A; [6],[7] tail/head of pool B
     uint32_t* const ctrl = A0.queue;
-    float4* const rec_a = A0.cont_out; float4* const rec_b = A0.cont_out + (size_t)A0.cont_capacity * 4;
-    const uint32_t passes = A.max_bounces < A0.cont_passes ? A.max_bounces : A0.cont_passes;
-    // pass 0
-    A.queue = ctrl; A.cont_out = rec_a; A.cont_out_count = ctrl + 8;
-    A.flush_threshold = passes > 0 ? A0.flush_threshold : 0u;
+    float4* const pool_a = A0.pool; float4* const pool_b = A0.pool + (size_t)A0.pool_capacity * 4;
+    uint32_t* const flags_a = A0.pool_flags; uint32_t* const flags_b = A0.pool_flags + A0.pool_capacity;
+    const uint32_t passes = A.max_bounces == 0u ? 0u : (A0.cont_passes < 3u ? A0.cont_passes : 3u);
+    if (passes > 0u) {
+        e = hipMemsetAsync(A0.pool_flags, 0, (size_t)A0.pool_capacity * 2u * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
+    // pass 0: pixel-samples; sparse wavefronts donate into pool A, dense / empty ones adopt from it
+    A.queue = ctrl; A.pool = pool_a; A.pool_flags = flags_a; A.pool_ctrl = ctrl + 4;
+    A.flush_threshold = passes > 0u ? A0.flush_threshold : 0u;
     if (k0) { e = hipEventRecord(k0, stream); if (e != hipSuccess) return e; }
     if (stats) hipLaunchKernelGGL((trace_paths_kernel<true, false>), dim3(grid_blocks), dim3(PT_MEGA_BLOCK), 0, stream, A);
     else       hipLaunchKernelGGL((trace_paths_kernel<false, false>), dim3(grid_blocks), dim3(PT_MEGA_BLOCK), 0, stream, A);
     e = hipGetLastError(); if (e != hipSuccess) return e;
-    // continuation passes: each record advances by at least one closest ray per pass; the last pass never flushes
+    // continuation passes pick up what is left in the previous pool; the last one never donates
     for (uint32_t pass = 1; pass <= passes && !A0.drop_cont; ++pass) {
         const bool odd = (pass & 1u) != 0u;
         A.queue = ctrl + pass;
-        A.cont_in = odd ? rec_a : rec_b; A.cont_in_count = ctrl + (odd ? 8 : 9);
-        A.cont_out = odd ? rec_b : rec_a; A.cont_out_count = ctrl + (odd ? 9 : 8);
-        A.flush_threshold = (pass < passes) ? (A0.flush_threshold >> pass) : 0u;
-        if (pass >= 2) { e = hipMemsetAsync(A.cont_out_count, 0, sizeof(uint32_t), stream); if (e != hipSuccess) return e; }
+        A.in_pool = odd ? pool_a : pool_b; A.in_ctrl = ctrl + (odd ? 4 : 6);
+        A.pool = odd ? pool_b : pool_a; A.pool_flags = odd ? flags_b : flags_a; A.pool_ctrl = ctrl + (odd ? 6 : 4);
+        A.flush_threshold = (pass < passes) ? A0.flush_threshold : 0u;
+        if (pass == 2u && passes > 2u) {   // pool A is reused as the output of pass 2
+            e = hipMemsetAsync(flags_a, 0, (size_t)A0.pool_capacity * sizeof(uint32_t), stream); if (e != hipSuccess) return e;
+            e = hipMemsetAsync(ctrl + 4, 0, 2 * sizeof(uint32_t), stream); if (e != hipSuccess) return e;
+        }
         if (stats) hipLaunchKernelGGL((trace_paths_kernel<true, true>), dim3(grid_blocks), dim3(PT_MEGA_BLOCK), 0, stream, A);
         else       hipLaunchKernelGGL((trace_paths_kernel<false, true>), dim3(grid_blocks), dim3(PT_MEGA_BLOCK), 0, stream, A);
         e = hipGetLastError(); if (e != hipSuccess) return e;

@@ -7,7 +7,7 @@
 const path = require("path");
 
 // overlapped frame slots need more than ROCm's default 4 hardware queues (read at HIP runtime init)
-if (process.env.GPU_MAX_HW_QUEUES === undefined) process.env.GPU_MAX_HW_QUEUES = "8";
+if (process.env.GPU_MAX_HW_QUEUES === undefined) process.env.GPU_MAX_HW_QUEUES = "12";
 let addon = null;
 function native() {
   if (!addon) addon = require(path.join(__dirname, "..", "napi", "mi355pt.node"));   // throws loudly when not built
