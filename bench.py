@@ -77,8 +77,8 @@ def cpu_baseline_node(tris, bvh4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
@@ -223,7 +223,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "trace_paths_kernel (persistent megakernel)", "kernel_avg_ms": round(k_avg_ms, 4),
-                         "note": "per-launch duration by hipEvents on the launch stream; up to %d frames' trace kernels overlap on side streams, so a launch's duration exceeds ms_per_step" % int(os.environ.get("PT_TUNE_SLOTS", "6")),
+                         "note": "per-launch duration by hipEvents on the launch stream; up to %d frames' trace kernels overlap on side streams, so a launch's duration exceeds ms_per_step" % int(os.environ.get("PT_TUNE_SLOTS", "8" if sharded else "3")),
                          "achieved_from_throughput": round(my_bytes * args.steps / elapsed / 1e9, 2),
                          "algorithmic_bytes_per_launch": my_bytes,
                          "counters": {k: my_stats[k] for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples")}},

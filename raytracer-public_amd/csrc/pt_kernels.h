@@ -15,7 +15,7 @@
 #define PT_MEGA_WAVES_PER_SIMD 6   // resident 256-thread blocks per CU = waves per SIMD
 #endif
 #ifndef PT_FRAME_SLOTS
-#define PT_FRAME_SLOTS 8            // frames whose trace phases may be in flight at once (side streams)
+#define PT_FRAME_SLOTS 3            // whole frames whose trace phases may be in flight at once (side streams); tile-sharded frames use 8
 #endif
 #ifndef PT_MEGA_BLOCK
 #define PT_MEGA_BLOCK 64           // threads per workgroup of the persistent kernel: single-wave groups free their CU slot as soon as the wave drains
@@ -24,7 +24,7 @@
 #define PT_SHADE_THRESHOLD 8       // shade when this many lanes of a wavefront wait with a finished ray
 #endif
 #ifndef PT_FLUSH_THRESHOLD
-#define PT_FLUSH_THRESHOLD 24      // once the queue is dry, a wavefront with fewer live lanes hands its paths to the next pass
+#define PT_FLUSH_THRESHOLD 0       // >0: once the queue is dry, a wavefront with fewer live lanes donates its paths to the next pass (measured: no gain at <= 4 frame slots, so off)
 #endif
 #ifndef PT_MAX_CONT_PASSES
 #define PT_MAX_CONT_PASSES 1       // continuation passes after pass 0 (the last one runs every path to its end)
