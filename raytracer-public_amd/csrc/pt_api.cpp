@@ -483,7 +483,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         A.perm_cols = (A.num_batches + 63u) / 64u;
         A.total_items = A.perm_cols * 64u * 64u;
         A.chunk_items = tune("PT_TUNE_CHUNK", 512u);
-        A.shade_threshold = tune("PT_TUNE_SHADE", PT_SHADE_THRESHOLD); A.fill_threshold = tune("PT_TUNE_FILL", PT_FILL_THRESHOLD);
+        A.shade_threshold = tune("PT_TUNE_SHADE", PT_SHADE_THRESHOLD); A.fill_threshold = tune("PT_TUNE_FILL", PT_FILL_THRESHOLD); A.leaf_threshold = tune("PT_TUNE_LEAF", PT_LEAF_THRESHOLD);
         A.flush_threshold = tune("PT_TUNE_FLUSH", sharded ? 0u : PT_FLUSH_THRESHOLD);   // sharded frames are too small to profit from a second pass A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES); A.drop_cont = tune("PT_TUNE_DROPCONT", 0u); A.adopt = tune("PT_TUNE_ADOPT", 0u);
         // frame slot (instrumented launches always use slot 0 and are not overlapped)
         int want_slots = int(tune("PT_TUNE_SLOTS", sharded ? 8u : PT_FRAME_SLOTS));   // small sharded frames need more of them in flight

@@ -29,6 +29,9 @@
 #ifndef PT_MAX_CONT_PASSES
 #define PT_MAX_CONT_PASSES 1       // continuation passes after pass 0 (the last one runs every path to its end)
 #endif
+#ifndef PT_LEAF_THRESHOLD
+#define PT_LEAF_THRESHOLD 1        // >1 postpones the triangle test until that many lanes wait at a leaf (measured slower: the step is latency-, not issue-bound)
+#endif
 #ifndef PT_FILL_THRESHOLD
 #define PT_FILL_THRESHOLD 8        // regenerate when this many lanes of a wavefront are without a path
 #endif
@@ -73,7 +76,7 @@ struct RenderArgs {
     float4*   pool; uint32_t* pool_flags; uint32_t* pool_ctrl;      // ctrl: [0] reserved tail, [1] claimed head
     const float4* in_pool; const uint32_t* in_ctrl;                  // previous pass's pool (continuation passes)
     uint32_t  pool_capacity, flush_threshold, cont_passes;
-    uint32_t  shade_threshold, fill_threshold;
+    uint32_t  shade_threshold, fill_threshold, leaf_threshold;
     uint32_t  adopt;            // 1: dense / empty wavefronts adopt donated paths within the launch; 0: donations wait for the next pass
     uint32_t  drop_cont;        // timing experiments only: discard flushed paths (wrong image)
 };
