@@ -63,6 +63,7 @@ struct PtContext {
     struct FrameSlot {
         hipStream_t side = nullptr; hipEvent_t resolved = nullptr, done = nullptr; bool used = false;
         DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<float4> cont; DevBuf<uint32_t> flags;
+        const void* primed_ptr = nullptr; size_t primed_samples = 0;   // what the resident prefill covers
     };
     static constexpr int kMaxSlots = 16;
     FrameSlot slots[kMaxSlots]; int num_slots = 0; uint32_t next_slot = 0;
@@ -502,6 +503,11 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         A.pool_capacity = grid_lanes * 2u;           // donations can repeat; a full pool just stops donating
         PT_HIP(ctx, sl.cont.ensure(A.cont_passes ? size_t(A.pool_capacity) * 4u * 2u : 4u));
         PT_HIP(ctx, sl.flags.ensure(A.cont_passes ? size_t(A.pool_capacity) * 2u : 4u));
+        {   // the resolve pass re-primes the slot; prime explicitly only when the buffer or the frame shape changed
+            const size_t n_samples = size_t(A.num_batches) * 64u;
+            A.prime = (sl.primed_ptr != (const void*)sl.samples.ptr || sl.primed_samples != n_samples || stats || tune("PT_TUNE_FOLD", 1u) == 0u) ? 1u : 0u;
+            sl.primed_ptr = sl.samples.ptr; sl.primed_samples = n_samples;
+        }
         A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr;
         if (stats) {
             const uint32_t waves = grid_lanes / 64u;

@@ -77,6 +77,7 @@ struct RenderArgs {
     const float4* in_pool; const uint32_t* in_ctrl;                  // previous pass's pool (continuation passes)
     uint32_t  pool_capacity, flush_threshold, cont_passes;
     uint32_t  shade_threshold, fill_threshold, leaf_threshold;
+    uint32_t  prime;            // 1: launch_trace must zero the control block and prefill the samples itself
     uint32_t  adopt;            // 1: dense / empty wavefronts adopt donated paths within the launch; 0: donations wait for the next pass
     uint32_t  drop_cont;        // timing experiments only: discard flushed paths (wrong image)
 };

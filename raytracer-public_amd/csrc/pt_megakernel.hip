@@ -450,10 +450,14 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
     if (px >= A.width || py >= A.height) return;
     const size_t out_index = A.compact ? (size_t)idx : ((size_t)py * A.width + px);
     F3 sum = f3(0.0f, 0.0f, 0.0f);
+    const float bg = 0.0f + 1.0f * kBgPrimary;
     for (uint32_t s = 0; s < A.spp; ++s) {
-        const float4 v = A.samples[((size_t)slot * A.spp + s) * 64u + p];
+        float4* sp = A.samples + ((size_t)slot * A.spp + s) * 64u + p;
+        const float4 v = *sp;
         sum = sum + f3(v.x, v.y, v.z);
+        *sp = make_float4(bg, bg, bg, 1.0f);     // leave the slot primed for its next frame (no separate prefill pass)
     }
+    if (idx == 0u) { for (int k = 0; k < 8; ++k) A.queue[k] = 0u; }   // and its control block rewound
     float count = (float)A.spp;
     if (A.accum) {
         const float4 acc = A.accumulate ? A.accum[out_index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -476,13 +480,17 @@ __global__ __launch_bounds__(256) void prefill_samples_kernel(float4* __restrict
 // are recorded immediately around the trace_paths_kernel launches.
 hipError_t launch_trace(const RenderArgs& A0, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1) {
     RenderArgs A = A0;
-    // control block: [0] item cursor pass 0, [1..] cursors of the continuation passes, [8], [9] record counts (ping-pong)
-    hipError_t e = hipMemsetAsync(A.queue, 0, 16 * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
     if (A.total_items == 0u) return hipSuccess;
-    const uint32_t n_samples = A.num_batches * 64u;
-    hipLaunchKernelGGL(prefill_samples_kernel, dim3(2048), dim3(256), 0, stream, A.samples, n_samples);
-    e = hipGetLastError(); if (e != hipSuccess) return e;
+    if (A0.prime) {
+        // first use of this slot's buffers (or a new frame shape): zero the control block and prefill the sample
+        // buffer; afterwards resolve_kernel leaves both ready for the slot's next frame
+        e = hipMemsetAsync(A.queue, 0, 16 * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        const uint32_t n_samples = A.num_batches * 64u;
+        hipLaunchKernelGGL(prefill_samples_kernel, dim3(2048), dim3(256), 0, stream, A.samples, n_samples);
+        e = hipGetLastError(); if (e != hipSuccess) return e;
+    }
     // control block (u32): [0..3] item cursors of the passes; [4],[5] tail/head of pool A; [6],[7] tail/head of pool B
     uint32_t* const ctrl = A0.queue;
     float4* const pool_a = A0.pool; float4* const pool_b = A0.pool + (size_t)A0.pool_capacity * 4;
