@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--verify", action="store_true", help="rank 0: check the gathered frame bit-for-bit against a whole-frame render")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -198,6 +199,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    verified = None
+    if args.verify and rank == 0:
+        with torch.cuda.stream(stream):
+            got = ctx.read_radiance(width, height).copy()           # last de-interleaved (or whole) frame
+            ctx.render(ctx.make_params(width, height, mode=rt.PT_MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED))
+            want = ctx.read_radiance(width, height)
+        verified = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+        if not verified:
+            raise SystemExit("bench.py --verify: gathered frame differs from the whole-frame render")
+
     if rank == 0:
         samples_per_step = width * height * SPP
         value = samples_per_step * args.steps / elapsed / 1e6
@@ -214,7 +225,7 @@ def main():
             "metric": "Msamples/sec @1920x1080 Stanford-Dragon-class, 4 spp, 8 bounces",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "verified": verified,
             "config": {"workload": "C2: dragon-class procedural closed mesh (%d tris, seed %d; dragon.glb absent), native LBVH2->BVH4, %dx%d, %d spp, %d bounces, camera (0,0,2.5) identity quat FOV 70"
                                    % (NUM_TRIS, SCENE_SEED, width, height, SPP, BOUNCES),
                        "triangles": NUM_TRIS, "bvh4_nodes": ctx.scene_info()["numNodes4"], "width": width, "height": height,

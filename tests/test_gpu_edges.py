@@ -139,3 +139,18 @@ def test_full_size_c5_4k_accumulate_smoke(rt, gpu_ctx_full):
     assert (img[..., 0] > 0.011).mean() > 0.08                                     # the object is there
     ms = ctx.last_render_ms()
     assert ms > 0
+
+
+def test_bench_two_ranks_gloo_rehearsal_verifies_gathered_frame():
+    """bench.py's N > 1 path end to end on the one-GPU box: two processes share cuda:0, the gather is staged
+    through gloo (PT_BENCH_BACKEND=gloo), rank 0 de-interleaves on the device and --verify compares the
+    result bit-for-bit with a whole-frame render."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                   "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--verify",
+                                   "--width", "640", "--height", "360"], env=env, cwd=root, text=True, stderr=subprocess.STDOUT, timeout=600)
+    line = [l for l in out.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["verified"] is True and res["value"] > 0 and res["scaling"] == "strong"
