@@ -67,6 +67,8 @@ struct PtContext {
     };
     static constexpr int kMaxSlots = 16;
     FrameSlot slots[kMaxSlots]; int num_slots = 0; uint32_t next_slot = 0;
+    // frames queued for one batched launch (pt_set_batch): launched when full or when anything needs their result
+    uint32_t batch_size = 1; uint32_t pending = 0; ptk::RenderArgs pendingA; bool pending_ring = false;
     DevBuf<unsigned long long> d_wave_times; uint32_t wave_times_n = 0;
     int num_cus = 0;
     DevBuf<unsigned long long> d_stats;
@@ -119,6 +121,85 @@ int upload_wide(PtContext* ctx, const uint32_t* bvh4, uint64_t words) {
     return PT_OK;
 }
 
+// Launch the queued frames as one persistent launch (trace on a side stream, resolve on the main stream).
+int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count) {
+    if (!ctx->pending) return PT_OK;
+    ptk::RenderArgs A = ctx->pendingA;
+    const uint32_t nf = ctx->pending;
+    ctx->pending = 0;
+    const bool ring = ctx->ring_used + 2 <= ctx->ring.size();
+    hipEvent_t e0 = ring ? ctx->ring[ctx->ring_used] : ctx->ev_start, e1 = ring ? ctx->ring[ctx->ring_used + 1] : ctx->ev_stop;
+    uint32_t grid = ptk::megakernel_grid(ctx->num_cus > 0 ? ctx->num_cus : 256);
+    // a tile-sharded frame is a fraction of the work: fewer, denser wavefronts (measured: 1/8 frame best at grid/4);
+    // a batch of nf such frames is nf times the work again
+    {
+        uint32_t div = tune("PT_TUNE_GRIDDIV", count >= 8u ? 4u : (count >= 2u ? 2u : 1u));
+        if (nf > 1u) div = div > nf ? div / nf : 1u;
+        if (div > 1u) grid = (grid + div - 1u) / div;
+    }
+    const uint32_t grid_lanes = grid * ptk::megakernel_block();
+    A.num_frames = nf;
+    A.batches_per_frame = A.num_tiles * A.spp;
+    A.num_batches = A.batches_per_frame * nf;
+    A.perm_cols = (A.num_batches + 63u) / 64u;
+    A.total_items = A.perm_cols * 64u * 64u;
+    A.chunk_items = tune("PT_TUNE_CHUNK", 512u);
+    A.shade_threshold = tune("PT_TUNE_SHADE", PT_SHADE_THRESHOLD); A.fill_threshold = tune("PT_TUNE_FILL", PT_FILL_THRESHOLD); A.leaf_threshold = tune("PT_TUNE_LEAF", PT_LEAF_THRESHOLD);
+    A.flush_threshold = tune("PT_TUNE_FLUSH", sharded ? 0u : PT_FLUSH_THRESHOLD);   // sharded frames are too small to profit from a second pass
+    A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES); A.drop_cont = tune("PT_TUNE_DROPCONT", 0u); A.adopt = tune("PT_TUNE_ADOPT", 0u);
+    // frame slot (instrumented launches always use slot 0 and are not overlapped)
+    int want_slots = int(tune("PT_TUNE_SLOTS", sharded && nf == 1u ? 8u : PT_FRAME_SLOTS));   // small sharded frames need more of them in flight
+    if (want_slots < 1) want_slots = 1;
+    if (want_slots > PtContext::kMaxSlots) want_slots = PtContext::kMaxSlots;
+    ctx->num_slots = want_slots;
+    PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(want_slots))];
+    if (!sl.side) {
+        PT_HIP(ctx, hipStreamCreateWithFlags(&sl.side, hipStreamNonBlocking));
+        PT_HIP(ctx, hipEventCreateWithFlags(&sl.resolved, hipEventDisableTiming));
+        PT_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    PT_HIP(ctx, sl.queue.ensure(16));
+    PT_HIP(ctx, sl.samples.ensure(size_t(A.num_batches) * 64u));
+    PT_HIP(ctx, sl.spill.ensure(size_t(grid_lanes) * size_t(64 - PT_SHORT_STACK)));
+    A.pool_capacity = grid_lanes * 2u;           // donations can repeat; a full pool just stops donating
+    PT_HIP(ctx, sl.cont.ensure(A.cont_passes ? size_t(A.pool_capacity) * 4u * 2u : 4u));
+    PT_HIP(ctx, sl.flags.ensure(A.cont_passes ? size_t(A.pool_capacity) * 2u : 4u));
+    {   // the resolve pass re-primes the slot; prime explicitly only when the buffer or the frame shape changed
+        const size_t n_samples = size_t(A.num_batches) * 64u;
+        A.prime = (sl.primed_ptr != (const void*)sl.samples.ptr || sl.primed_samples != n_samples || stats || tune("PT_TUNE_FOLD", 1u) == 0u) ? 1u : 0u;
+        sl.primed_ptr = sl.samples.ptr; sl.primed_samples = n_samples;
+    }
+    A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr;
+    if (stats) {
+        const uint32_t waves = grid_lanes / 64u;
+        PT_HIP(ctx, ctx->d_wave_times.ensure(size_t(waves) * 16u));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(waves) * 16u * 8u, ctx->stream));
+        A.wave_times = ctx->d_wave_times.ptr; ctx->wave_times_n = waves;
+    }
+    // Dependencies: scene uploads are host-synchronous, so the trace only has to wait for the resolve
+    // that last read this slot's sample buffer (NOT for the previous frame's resolve -- that is what
+    // lets consecutive frames overlap); the resolve on the main stream waits for the trace.
+    if (!ring) PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    if (sl.used) PT_HIP(ctx, hipStreamWaitEvent(sl.side, sl.resolved, 0));
+    // timing ring: events tightly around the trace kernels on the stream they run on
+    PT_HIP(ctx, ptk::launch_trace(A, stats, grid, sl.side, ring ? e0 : nullptr, ring ? e1 : nullptr));
+    PT_HIP(ctx, hipEventRecord(sl.done, sl.side));
+    PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.done, 0));
+    PT_HIP(ctx, ptk::launch_resolve(A, ctx->stream));
+    PT_HIP(ctx, hipEventRecord(sl.resolved, ctx->stream)); sl.used = true;
+    if (!ring) PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    if (ring) ctx->ring_used += 2;
+    ctx->timed = !ring;
+    return PT_OK;
+}
+
+int flush_pending(PtContext* ctx) {
+    if (!ctx->pending) return PT_OK;
+    const uint32_t count = ctx->tiles_count ? ctx->tiles_count : 1u;
+    const bool sharded = ctx->pendingA.compact != 0u;
+    return flush_pending_stats(ctx, false, sharded, sharded ? count : 1u);
+}
+
 } // namespace
 
 extern "C" {
@@ -155,6 +236,7 @@ int pt_create(int device_ordinal, PtContext** out) {
 void pt_destroy(PtContext* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)flush_pending(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->d_tris9.release(); ctx->d_trirec.release(); ctx->d_bvh2.release(); ctx->d_bvh4.release(); ctx->d_wide.release();
     ctx->d_spheres.release(); ctx->d_morton.release(); ctx->d_triidx.release(); ctx->d_parent.release(); ctx->d_flags.release();
@@ -176,6 +258,7 @@ void pt_destroy(PtContext* ctx) {
 
 int pt_set_stream(PtContext* ctx, void* hip_stream) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     ctx->timed = false;
@@ -190,6 +273,7 @@ int pt_get_stream(PtContext* ctx, void** hip_stream) {
 
 int pt_synchronize(PtContext* ctx) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
@@ -264,6 +348,7 @@ int pt_scene_procedural(uint32_t kind, uint32_t seed, uint32_t num_tris, float* 
 
 int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     if (num_tris && !tris) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_triangles: null triangles");
     if (num_tris >= 0x7fffffffu) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_triangles: too many triangles for the 31-bit leaf index");
     PT_HIP(ctx, ctx->d_tris9.ensure(size_t(num_tris) * 9));
@@ -284,6 +369,7 @@ int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris) {
 
 int pt_build_lbvh2(PtContext* ctx, const uint32_t* morton_sorted, const uint32_t* tri_index_sorted) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     if (!ctx->have_tris) return fail(ctx, PT_ERR_NO_SCENE, "pt_build_lbvh2: no triangles uploaded");
     const uint32_t n = ctx->num_tris;
     uint32_t nn2 = 0; uint64_t bytes = 0;
@@ -320,6 +406,7 @@ int pt_read_bvh2(PtContext* ctx, uint32_t* dst, uint64_t bytes) {
 
 int pt_set_bvh4(PtContext* ctx, const uint32_t* bvh4, uint64_t words) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     if (!bvh4 || words < 1) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_bvh4: empty buffer");
     ctx->accum_count = 0;
     return upload_wide(ctx, bvh4, words);
@@ -327,6 +414,7 @@ int pt_set_bvh4(PtContext* ctx, const uint32_t* bvh4, uint64_t words) {
 
 int pt_set_bvh2(PtContext* ctx, const uint32_t* bvh2, uint64_t words) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     if (!ctx->have_tris) return fail(ctx, PT_ERR_NO_SCENE, "pt_set_bvh2: upload triangles first");
     uint32_t nn2 = 0; uint64_t bytes = 0; pt_compute_bvh2_sizing(ctx->num_tris, &nn2, &bytes);
     if (!bvh2 || words * 4 < bytes || bvh2[0] != nn2) return fail(ctx, PT_ERR_BAD_BVH, "pt_set_bvh2: buffer does not match 2N-1 nodes of the uploaded triangles");
@@ -342,6 +430,7 @@ int pt_set_bvh2(PtContext* ctx, const uint32_t* bvh2, uint64_t words) {
 
 int pt_build_bvh(PtContext* ctx) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     if (!ctx->have_tris) return fail(ctx, PT_ERR_NO_SCENE, "pt_build_bvh: no triangles uploaded");
     const uint32_t n = ctx->num_tris;
     if (n == 0) {                                   // PathTracer.js:701-707: empty BVH4
@@ -376,6 +465,7 @@ int pt_read_bvh4(PtContext* ctx, uint32_t* dst, uint64_t bytes) {
 
 int pt_set_spheres(PtContext* ctx, const float* xyzr, uint32_t num_spheres) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     if (num_spheres && !xyzr) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_spheres: null spheres");
     PT_HIP(ctx, ctx->d_spheres.ensure(num_spheres));
     if (num_spheres) PT_HIP(ctx, hipMemcpy(ctx->d_spheres.ptr, xyzr, size_t(num_spheres) * 16, hipMemcpyHostToDevice));
@@ -476,64 +566,39 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     hipEvent_t e0 = ring ? ctx->ring[ctx->ring_used] : ctx->ev_start, e1 = ring ? ctx->ring[ctx->ring_used + 1] : ctx->ev_stop;
     const int kmode = p->mode == PT_MODE_REFERENCE_PACKET ? PT_KMODE_PACKET : (p->mode == PT_MODE_REFERENCE ? PT_KMODE_REFERENCE : PT_KMODE_PATH);
     if (kmode == PT_KMODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute) {
-        uint32_t grid = ptk::megakernel_grid(ctx->num_cus > 0 ? ctx->num_cus : 256);
-        // a tile-sharded frame is a fraction of the work: fewer, denser wavefronts (measured: 1/8 frame best at grid/4)
-        { const uint32_t div = tune("PT_TUNE_GRIDDIV", count >= 8u ? 4u : (count >= 2u ? 2u : 1u)); if (div > 1u) grid = (grid + div - 1u) / div; }
-        const uint32_t grid_lanes = grid * ptk::megakernel_block();
-        A.num_batches = A.num_tiles * p->spp;
-        A.perm_cols = (A.num_batches + 63u) / 64u;
-        A.total_items = A.perm_cols * 64u * 64u;
-        A.chunk_items = tune("PT_TUNE_CHUNK", 512u);
-        A.shade_threshold = tune("PT_TUNE_SHADE", PT_SHADE_THRESHOLD); A.fill_threshold = tune("PT_TUNE_FILL", PT_FILL_THRESHOLD); A.leaf_threshold = tune("PT_TUNE_LEAF", PT_LEAF_THRESHOLD);
-        A.flush_threshold = tune("PT_TUNE_FLUSH", sharded ? 0u : PT_FLUSH_THRESHOLD);   // sharded frames are too small to profit from a second pass A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES); A.drop_cont = tune("PT_TUNE_DROPCONT", 0u); A.adopt = tune("PT_TUNE_ADOPT", 0u);
-        // frame slot (instrumented launches always use slot 0 and are not overlapped)
-        int want_slots = int(tune("PT_TUNE_SLOTS", sharded ? 8u : PT_FRAME_SLOTS));   // small sharded frames need more of them in flight
-        if (want_slots < 1) want_slots = 1;
-        if (want_slots > PtContext::kMaxSlots) want_slots = PtContext::kMaxSlots;
-        ctx->num_slots = want_slots;
-        PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(want_slots))];
-        if (!sl.side) {
-            PT_HIP(ctx, hipStreamCreateWithFlags(&sl.side, hipStreamNonBlocking));
-            PT_HIP(ctx, hipEventCreateWithFlags(&sl.resolved, hipEventDisableTiming));
-            PT_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        // ---- persistent megakernel: frames are queued and launched in batches of ctx->batch_size
+        ptk::FrameParams fp; std::memset(&fp, 0, sizeof(fp));
+        std::memcpy(fp.cam, p->cam_pos, 12); std::memcpy(fp.quat, p->cam_quat, 16);
+        fp.focal = p->focal; fp.aspect = p->aspect; fp.frame = p->frame; fp.seed = p->seed;
+        fp.accum_mode = A.accum ? (A.accumulate ? 2u : 1u) : 0u;
+        if (ctx->pending) {
+            const ptk::RenderArgs& Q = ctx->pendingA;   // a frame joins the open batch only if it has the same shape and targets
+            const bool same = Q.width == A.width && Q.height == A.height && Q.spp == A.spp && Q.max_bounces == A.max_bounces && Q.num_tris == A.num_tris &&
+                              Q.tiles == A.tiles && Q.num_tiles == A.num_tiles && Q.compact == A.compact && Q.accum == A.accum && !stats;
+            if (!same || ctx->pending >= PT_MAX_BATCH) { if (int rc = flush_pending(ctx)) return rc; }
         }
-        PT_HIP(ctx, sl.queue.ensure(16));
-        PT_HIP(ctx, sl.samples.ensure(size_t(A.num_batches) * 64u));
-        PT_HIP(ctx, sl.spill.ensure(size_t(grid_lanes) * size_t(64 - PT_SHORT_STACK)));
-        A.pool_capacity = grid_lanes * 2u;           // donations can repeat; a full pool just stops donating
-        PT_HIP(ctx, sl.cont.ensure(A.cont_passes ? size_t(A.pool_capacity) * 4u * 2u : 4u));
-        PT_HIP(ctx, sl.flags.ensure(A.cont_passes ? size_t(A.pool_capacity) * 2u : 4u));
-        {   // the resolve pass re-primes the slot; prime explicitly only when the buffer or the frame shape changed
-            const size_t n_samples = size_t(A.num_batches) * 64u;
-            A.prime = (sl.primed_ptr != (const void*)sl.samples.ptr || sl.primed_samples != n_samples || stats || tune("PT_TUNE_FOLD", 1u) == 0u) ? 1u : 0u;
-            sl.primed_ptr = sl.samples.ptr; sl.primed_samples = n_samples;
-        }
-        A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr;
-        if (stats) {
-            const uint32_t waves = grid_lanes / 64u;
-            PT_HIP(ctx, ctx->d_wave_times.ensure(size_t(waves) * 16u));
-            PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(waves) * 16u * 8u, ctx->stream));
-            A.wave_times = ctx->d_wave_times.ptr; ctx->wave_times_n = waves;
-        }
-        // Dependencies: scene uploads are host-synchronous, so the trace only has to wait for the resolve
-        // that last read this slot's sample buffer (NOT for the previous frame's resolve -- that is what
-        // lets consecutive frames overlap); the resolve on the main stream waits for the trace.
-        if (!ring) PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
-        if (sl.used) PT_HIP(ctx, hipStreamWaitEvent(sl.side, sl.resolved, 0));
-        // timing ring: events tightly around the trace kernels on the stream they run on
-        PT_HIP(ctx, ptk::launch_trace(A, stats, grid, sl.side, ring ? e0 : nullptr, ring ? e1 : nullptr));
-        PT_HIP(ctx, hipEventRecord(sl.done, sl.side));
-        PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.done, 0));
-        PT_HIP(ctx, ptk::launch_resolve(A, ctx->stream));
-        PT_HIP(ctx, hipEventRecord(sl.resolved, ctx->stream)); sl.used = true;
-        if (!ring) PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        if (!ctx->pending) { ctx->pendingA = A; ctx->pending_ring = false; }
+        ctx->pendingA.frames[ctx->pending] = fp; ctx->pendingA.outs[ctx->pending] = A.out;
+        ++ctx->pending;
+        ctx->timed = false;
+        if (stats || ctx->pending >= ctx->batch_size) return flush_pending_stats(ctx, stats, sharded, count);
+        return PT_OK;
     } else {
+        if (int rc = flush_pending(ctx)) return rc;
         PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
         PT_HIP(ctx, ptk::launch_render(A, kmode, stats, ctx->stream));
         PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
     }
     if (ring) ctx->ring_used += 2;
     ctx->timed = !ring;
+    return PT_OK;
+}
+
+int pt_set_batch(PtContext* ctx, uint32_t frames_per_launch) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
+    if (frames_per_launch < 1u || frames_per_launch > PT_MAX_BATCH) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_batch: 1..8 frames per launch");
+    ctx->batch_size = frames_per_launch;
     return PT_OK;
 }
 
@@ -551,6 +616,7 @@ int pt_timing_begin(PtContext* ctx, uint32_t capacity) {
 
 int pt_timing_collect(PtContext* ctx, float* ms, uint32_t capacity, uint32_t* count) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t n = ctx->ring_used / 2;
     uint32_t got = 0;
@@ -564,6 +630,7 @@ int pt_timing_collect(PtContext* ctx, float* ms, uint32_t capacity, uint32_t* co
 
 int pt_last_render_ms(PtContext* ctx, float* ms) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     if (!ms) return fail(ctx, PT_ERR_INVALID_ARG, "pt_last_render_ms: null output");
     if (!ctx->timed) return fail(ctx, PT_ERR_NO_SCENE, "pt_last_render_ms: nothing rendered yet");
     PT_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
@@ -573,6 +640,7 @@ int pt_last_render_ms(PtContext* ctx, float* ms) {
 
 int pt_get_stats(PtContext* ctx, PtStats* out) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     if (!out) return fail(ctx, PT_ERR_INVALID_ARG, "pt_get_stats: null output");
     if (!ctx->last_stats) return fail(ctx, PT_ERR_NO_SCENE, "pt_get_stats: last render did not run with PT_FLAG_STATS");
     unsigned long long h[8];
@@ -601,6 +669,7 @@ int pt_debug_wave_times(PtContext* ctx, unsigned long long* dst, uint32_t max_wa
 
 int pt_read_radiance(PtContext* ctx, float* dst, uint64_t dst_floats) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     if (!dst) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_radiance: null destination");
     const uint64_t need = uint64_t(ctx->out_w) * ctx->out_h * 4;
     if (need == 0) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_radiance: no full-frame result (render with tile_count <= 1 or call pt_deinterleave)");
@@ -612,6 +681,7 @@ int pt_read_radiance(PtContext* ctx, float* dst, uint64_t dst_floats) {
 
 int pt_read_rgba8(PtContext* ctx, uint8_t* dst, uint64_t dst_bytes) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     const uint64_t npx = uint64_t(ctx->out_w) * ctx->out_h;
     if (npx == 0) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_rgba8: no full-frame result");
     if (!dst || dst_bytes < npx * 4) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_rgba8: destination too small");
@@ -624,6 +694,7 @@ int pt_read_rgba8(PtContext* ctx, uint8_t* dst, uint64_t dst_bytes) {
 
 int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t dst_bytes) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     const uint64_t npx = uint64_t(ctx->out_w) * ctx->out_h;
     if (npx == 0) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_tonemapped: no full-frame result");
     if (!dst || dst_bytes < npx * 4) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_tonemapped: destination too small");
@@ -643,6 +714,7 @@ int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats) {
 
 int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     if (ctx->compact_floats == 0 || !(ctx->ext_compact || ctx->d_compact.ptr)) return fail(ctx, PT_ERR_NO_SCENE, "pt_compact_radiance: no tile-sharded render yet");
     if (device_ptr) *device_ptr = ctx->ext_compact ? (void*)ctx->ext_compact : (void*)ctx->d_compact.ptr;
     if (floats) *floats = ctx->compact_floats;
@@ -651,6 +723,7 @@ int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats) {
 
 int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride_floats, uint32_t width, uint32_t height, uint32_t tile_count) {
     if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
     if (!gathered_device || tile_count == 0 || (stride_floats & 3)) return fail(ctx, PT_ERR_INVALID_ARG, "pt_deinterleave: bad arguments");
     for (uint32_t r = 0; r < tile_count; ++r) {
         uint32_t nt = 0; pt_tile_layout(width, height, r, tile_count, &nt, nullptr);

@@ -61,6 +61,16 @@ __device__ __forceinline__ Ray primary_ray(const RenderArgs& A, float fx, float 
     return r;
 }
 
+__device__ __forceinline__ Ray primary_ray_fp(const RenderArgs& A, const FrameParams& fp, float fx, float fy) {   // renderer.wgsl:387-395
+    const float uvx = fx / (float)A.width, uvy = fy / (float)A.height;
+    const float px = __builtin_fmaf(uvx, 2.0f, -1.0f), py = __builtin_fmaf(uvy, 2.0f, -1.0f);
+    Ray r;
+    r.d = rotate_quat(normalize3(f3(px * fp.aspect, py, -fp.focal)), fp.quat);
+    r.o = f3(fp.cam[0], fp.cam[1], fp.cam[2]);
+    r.inv = safe_inv(r.d);
+    return r;
+}
+
 // slab test of one packed f16 box (renderer.wgsl:147-159); returns hit, writes tmin
 __device__ __forceinline__ bool slab(const Ray& r, uint32_t w0, uint32_t w1, uint32_t w2, float best, float& tmin_out) {
     const F3 mn = f3(half_lo(w0), half_hi(w0), half_lo(w1));

@@ -38,6 +38,15 @@
 
 namespace ptk {
 
+#define PT_MAX_BATCH 8
+// Per-frame part of the UBO for a batched launch (several consecutive frames traced by one persistent launch).
+struct FrameParams {
+    float cam[3]; float focal;
+    float quat[4];
+    float aspect; uint32_t frame; uint32_t seed;
+    uint32_t accum_mode;        // 0: no accumulation buffer, 1: restart the running sum, 2: add to it
+};
+
 // Passed by value as the kernel argument (lives in SGPRs / the kernarg segment).
 struct RenderArgs {
     // device scene, MI355X layouts
@@ -77,6 +86,9 @@ struct RenderArgs {
     const float4* in_pool; const uint32_t* in_ctrl;                  // previous pass's pool (continuation passes)
     uint32_t  pool_capacity, flush_threshold, cont_passes;
     uint32_t  shade_threshold, fill_threshold, leaf_threshold;
+    // batched launch: frames[i] / outs[i] for i < num_frames; items of frame i are batches [i*batches_per_frame, ...)
+    FrameParams frames[PT_MAX_BATCH]; float4* outs[PT_MAX_BATCH];
+    uint32_t  num_frames, batches_per_frame;
     uint32_t  prime;            // 1: launch_trace must zero the control block and prefill the samples itself
     uint32_t  adopt;            // 1: dense / empty wavefronts adopt donated paths within the launch; 0: donations wait for the next pass
     uint32_t  drop_cont;        // timing experiments only: discard flushed paths (wrong image)

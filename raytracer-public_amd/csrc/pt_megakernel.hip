@@ -66,7 +66,9 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
         in_base = head; in_count = tail > head ? tail - head : 0u;
     }
     const uint32_t total_items = CONT ? in_count : A.total_items;
-    const bool pool_on = A.flush_threshold != 0u;     // wave-uniform: this pass donates / adopts through A.pool
+    const bool pool_on = A.flush_threshold != 0u;
+    // per-frame parameters are read through the kernarg segment (per-lane index: lanes of one refill may straddle two frames)
+    const FrameParams* const frames = (const FrameParams*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(RenderArgs, frames));     // wave-uniform: this pass donates / adopts through A.pool
     const uint32_t chunk_items = CONT ? 64u : A.chunk_items;
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: this wave's private item range
     bool queue_empty = false;                 // wave-uniform
@@ -229,13 +231,15 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                         const bool in_range = q < A.num_batches;
                         const uint32_t item = q * 64u + (logical & 63u);
                         const uint32_t p = item & 63u;
-                        const uint32_t s = q % A.spp, slot = in_range ? q / A.spp : 0u;
+                        const uint32_t fid = in_range ? q / A.batches_per_frame : 0u, qq = q - fid * A.batches_per_frame;
+                        const uint32_t s = qq % A.spp, slot = in_range ? qq / A.spp : 0u;
                         const uint32_t tile = A.tiles ? A.tiles[slot] : slot;
                         const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
                         const uint32_t px = tx * 8u + (p & 7u), py = ty * 8u + (p >> 3);
                         if (in_range && px < A.width && py < A.height) {
-                            const uint32_t key = sample_key(A.seed, py * A.width + px, A.frame * A.spp + s);
-                            const Ray r = primary_ray(A, (float)px + rnd(key, 0, 0), (float)py + rnd(key, 0, 1));
+                            const FrameParams fp = frames[fid];
+                            const uint32_t key = sample_key(fp.seed, py * A.width + px, fp.frame * A.spp + s);
+                            const Ray r = primary_ray_fp(A, fp, (float)px + rnd(key, 0, 0), (float)py + rnd(key, 0, 1));
                             S.o = r.o; S.d = r.d; S.inv = r.inv;
                             S.key = key; S.item = item; S.bounce = 0u;
                             S.T = f3(1.0f, 1.0f, 1.0f); S.rad = f3(0.0f, 0.0f, 0.0f);
@@ -449,24 +453,30 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
     const uint32_t px = tx * 8u + (p & 7u), py = ty * 8u + (p >> 3);
     if (px >= A.width || py >= A.height) return;
     const size_t out_index = A.compact ? (size_t)idx : ((size_t)py * A.width + px);
-    F3 sum = f3(0.0f, 0.0f, 0.0f);
     const float bg = 0.0f + 1.0f * kBgPrimary;
-    for (uint32_t s = 0; s < A.spp; ++s) {
-        float4* sp = A.samples + ((size_t)slot * A.spp + s) * 64u + p;
-        const float4 v = *sp;
-        sum = sum + f3(v.x, v.y, v.z);
-        *sp = make_float4(bg, bg, bg, 1.0f);     // leave the slot primed for its next frame (no separate prefill pass)
+    const FrameParams* const frames = (const FrameParams*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(RenderArgs, frames));
+    float4* const* const outs = (float4* const*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(RenderArgs, outs));
+    // frames of a batched launch are resolved in submission order (the running sum of an accumulating sequence is order-dependent)
+    for (uint32_t fid = 0; fid < A.num_frames; ++fid) {
+        F3 sum = f3(0.0f, 0.0f, 0.0f);
+        for (uint32_t s = 0; s < A.spp; ++s) {
+            float4* sp = A.samples + (((size_t)fid * A.batches_per_frame + (size_t)slot * A.spp + s) * 64u + p);
+            const float4 v = *sp;
+            sum = sum + f3(v.x, v.y, v.z);
+            *sp = make_float4(bg, bg, bg, 1.0f);     // leave the slot primed for its next frame (no separate prefill pass)
+        }
+        float count = (float)A.spp;
+        const uint32_t am = frames[fid].accum_mode;
+        if (am != 0u) {
+            const float4 acc = (am == 2u) ? A.accum[out_index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            sum = f3(acc.x + sum.x, acc.y + sum.y, acc.z + sum.z);
+            count = acc.w + count;
+            A.accum[out_index] = make_float4(sum.x, sum.y, sum.z, count);
+        }
+        const float inv = 1.0f / count;
+        outs[fid][out_index] = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, 1.0f);
     }
     if (idx == 0u) { for (int k = 0; k < 8; ++k) A.queue[k] = 0u; }   // and its control block rewound
-    float count = (float)A.spp;
-    if (A.accum) {
-        const float4 acc = A.accumulate ? A.accum[out_index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        sum = f3(acc.x + sum.x, acc.y + sum.y, acc.z + sum.z);
-        count = acc.w + count;
-        A.accum[out_index] = make_float4(sum.x, sum.y, sum.z, count);
-    }
-    const float inv = 1.0f / count;
-    A.out[out_index] = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, 1.0f);
 }
 
 // every sample starts as the camera-ray miss value 0 + 1 * 0.01 (renderer.wgsl:410)

@@ -204,6 +204,57 @@ def test_sponza_class_interior_bit_exact(rt, orc, gpu_ctx):
     assert (ids != 0xFFFFFFFF).mean() > 0.99       # interior: (almost) every camera ray hits
 
 
+def test_batched_launch_equals_frame_by_frame(rt, gpu_ctx):
+    """pt_set_batch: several frames traced by one persistent launch give exactly the per-frame results
+    (each into the output target that was current at submission), including an accumulating sequence."""
+    import ctypes as C
+    tris = rt.procedural_scene(0, 20000)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    w, h, count = 200, 120, 2
+    hip = C.CDLL("libamdhip64.so")
+    nt, floats = rt.tile_layout(w, h, 0, count)
+    cams = [((0, 0, 2.5), (0, 0, 0, 1)), ((0.3, 0.1, 2.2), quat_yaw_pitch(0.1, 0.05)), ((-0.2, 0.2, 2.4), quat_yaw_pitch(-0.1, 0.0))]
+    def params(i, **kw):
+        return gpu_ctx.make_params(w, h, cams[i][0], cams[i][1], mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=5, frame=10 + i, **kw)
+    # reference: one launch per frame
+    want = []
+    for i in range(3):
+        gpu_ctx.render(params(i, tile_rank=0, tile_count=count))
+        ptr, fl = gpu_ctx.compact_radiance(); gpu_ctx.synchronize()
+        host = np.zeros(fl, np.float32)
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(fl * 4), 2) == 0
+        want.append(host)
+    # batched: three frames, three caller-owned compact buffers, one launch
+    bufs = []
+    for i in range(3):
+        p = C.c_void_p(); assert hip.hipMalloc(C.byref(p), C.c_size_t(floats * 4)) == 0; bufs.append(p)
+    gpu_ctx.set_batch(3)
+    for i in range(3):
+        gpu_ctx.set_compact_buffer(bufs[i].value, floats)
+        gpu_ctx.render(params(i, tile_rank=0, tile_count=count))
+    gpu_ctx.synchronize()
+    for i in range(3):
+        host = np.zeros(floats, np.float32)
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), bufs[i], C.c_size_t(floats * 4), 2) == 0
+        assert same_bits(host, want[i]), i
+    # a partial batch is launched by the read-back; accumulation order is the submission order
+    gpu_ctx.set_compact_buffer(0, 0)
+    gpu_ctx.set_batch(1)
+    for i in range(3):
+        gpu_ctx.render(params(0, accumulate=True) if i == 0 else gpu_ctx.make_params(w, h, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=5, frame=10 + i, accumulate=True))
+    ref = gpu_ctx.read_radiance().copy()
+    gpu_ctx.render(gpu_ctx.make_params(w, h, mode=rt.PT_MODE_REFERENCE))      # ends the accumulating sequence
+    gpu_ctx.set_batch(4)
+    for i in range(3):
+        gpu_ctx.render(params(0, accumulate=True) if i == 0 else gpu_ctx.make_params(w, h, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=5, frame=10 + i, accumulate=True))
+    got = gpu_ctx.read_radiance().copy()                                       # flushes the open batch of 3
+    gpu_ctx.set_batch(1)
+    for b in bufs:
+        hip.hipFree(b)
+    assert same_bits(got, ref)
+
+
 def test_error_paths(rt, gpu_ctx):
     fresh = rt.Context(0)
     with pytest.raises(rt.PtError) as e:
