@@ -161,6 +161,8 @@ int pt_render(PtContext* ctx, const PtRenderParams* params);
  * needs its result: pt_synchronize, any read-back, pt_compact_radiance / pt_deinterleave, scene changes.
  * Each frame still resolves into the output target that was current when it was submitted. */
 int pt_set_batch(PtContext* ctx, uint32_t frames_per_launch);
+/* Launch a partially filled batch now (asynchronous, no host synchronisation). */
+int pt_flush(PtContext* ctx);
 /* Device time of the last pt_render's kernel(s), by hipEvents on the stream it ran on.
  * Synchronises the stream. */
 int pt_last_render_ms(PtContext* ctx, float* ms);

@@ -60,7 +60,7 @@ EXPORTS = [
     "pt_compute_bvh2_sizing", "pt_compute_bvh4_sizing", "pt_morton_sort", "pt_collapse_lbvh2_to_bvh4",
     "pt_bvh2_to_bvh4_wide", "pt_file_write_u32", "pt_file_read_u32", "pt_scene_procedural",
     "pt_set_triangles", "pt_build_bvh", "pt_build_lbvh2", "pt_read_bvh2", "pt_set_bvh4", "pt_set_bvh2",
-    "pt_read_bvh4", "pt_set_spheres", "pt_scene_info", "pt_render", "pt_last_render_ms", "pt_set_batch", "pt_timing_begin", "pt_timing_collect", "pt_set_compact_buffer", "pt_get_stats", "pt_read_radiance",
+    "pt_read_bvh4", "pt_set_spheres", "pt_scene_info", "pt_render", "pt_last_render_ms", "pt_set_batch", "pt_flush", "pt_timing_begin", "pt_timing_collect", "pt_set_compact_buffer", "pt_get_stats", "pt_read_radiance",
     "pt_read_rgba8", "pt_read_tonemapped", "pt_tile_layout", "pt_compact_radiance", "pt_deinterleave",
 ]
 
@@ -263,6 +263,9 @@ class Context:
 
     def set_batch(self, frames_per_launch):
         self._ck(lib.pt_set_batch(self.h, C.c_uint32(frames_per_launch)))
+
+    def flush(self):
+        self._ck(lib.pt_flush(self.h))
 
     def timing_begin(self, capacity):
         self._ck(lib.pt_timing_begin(self.h, C.c_uint32(capacity)))

@@ -602,6 +602,11 @@ int pt_set_batch(PtContext* ctx, uint32_t frames_per_launch) {
     return PT_OK;
 }
 
+int pt_flush(PtContext* ctx) {
+    if (int rc = bind(ctx)) return rc;
+    return flush_pending(ctx);
+}
+
 int pt_timing_begin(PtContext* ctx, uint32_t capacity) {
     if (int rc = bind(ctx)) return rc;
     while (ctx->ring.size() < size_t(capacity) * 2) {

@@ -12,7 +12,8 @@ if os.environ.get("PB_TORCH") == "2":
 ctx.set_triangles(tris); ctx.build_bvh()
 tc = int(os.environ.get('PB_TILES', '1'))
 p = ctx.make_params(1920, 1080, mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, tile_rank=0, tile_count=tc)
-for _ in range(8): ctx.render(p)
+B = int(os.environ.get('PB_BATCH', '1')); ctx.set_batch(B)
+for _ in range(8 * B): ctx.render(p)
 ctx.synchronize()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 if os.environ.get("PB_RING"): ctx.timing_begin(n)
@@ -22,5 +23,5 @@ ctx.synchronize()
 dt = time.perf_counter() - t0
 if os.environ.get("PB_RING"):
     ms = ctx.timing_collect(n); print("ring: kernel avg %.3f ms" % ms.mean())
-print("tiles 1/%d griddiv=%s " % (tc, os.environ.get("PT_TUNE_GRIDDIV", "1")), end="")
+print("tiles 1/%d batch=%d " % (tc, B), end="")
 print("slots=%s: %.3f ms/frame, %.0f Msamples/s" % (os.environ.get("PT_TUNE_SLOTS", "default"), dt / n * 1e3, 1920 * 1080 * 4 * n / dt / 1e6))
