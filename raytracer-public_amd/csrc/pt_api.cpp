@@ -222,7 +222,12 @@ int pt_create(int device_ordinal, PtContext** out) {
     if (e != hipSuccess) return fail_hip(nullptr, e, "hipSetDevice");
     PtContext* ctx = new PtContext();
     ctx->device = dev;
-    e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    {   // the context's stream carries the short resolve passes: highest priority, so their blocks are placed ahead of
+        // the persistent trace launches (normal-priority side streams) whenever CU slots free up
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, hi);
+    }
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop);
     if (e == hipSuccess) e = ctx->d_stats.ensure(16);

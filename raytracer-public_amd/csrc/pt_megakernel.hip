@@ -505,7 +505,7 @@ hipError_t launch_trace(const RenderArgs& A0, bool stats, uint32_t grid_blocks, 
     uint32_t* const ctrl = A0.queue;
     float4* const pool_a = A0.pool; float4* const pool_b = A0.pool + (size_t)A0.pool_capacity * 4;
     uint32_t* const flags_a = A0.pool_flags; uint32_t* const flags_b = A0.pool_flags + A0.pool_capacity;
-    const uint32_t passes = A.max_bounces == 0u ? 0u : (A0.cont_passes < 3u ? A0.cont_passes : 3u);
+    const uint32_t passes = (A.max_bounces == 0u || A0.flush_threshold == 0u) ? 0u : (A0.cont_passes < 3u ? A0.cont_passes : 3u);   // nothing is donated without a flush threshold
     if (passes > 0u) {
         e = hipMemsetAsync(A0.pool_flags, 0, (size_t)A0.pool_capacity * 2u * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
