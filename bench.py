@@ -103,7 +103,10 @@ def main():
     device = local_rank % max(n_dev, 1)
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     width, height = args.width, args.height
     tris = rt.procedural_scene(rt.SCENE_DRAGON_CLASS, NUM_TRIS, SCENE_SEED)
