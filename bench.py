@@ -125,7 +125,7 @@ def main():
     # Frames are submitted in batches: the library traces `batch` consecutive frames with one persistent
     # launch (pt_set_batch), which amortises the sparse tail of a frame -- essential for the small per-GPU
     # shares of a sharded run.  The RCCL gather then moves one batch at a time (fewer, larger collectives).
-    batch = int(os.environ.get("PT_BENCH_BATCH", "8"))
+    batch = int(os.environ.get("PT_BENCH_BATCH", "0")) or args.steps // 8     # short runs: smaller batches, shorter fill / drain
     batch = max(1, min(8, batch))
     ctx.set_batch(1)
     if sharded:
