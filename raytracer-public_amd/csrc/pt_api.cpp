@@ -146,7 +146,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     A.chunk_items = tune("PT_TUNE_CHUNK", 512u);
     A.shade_threshold = tune("PT_TUNE_SHADE", PT_SHADE_THRESHOLD); A.fill_threshold = tune("PT_TUNE_FILL", PT_FILL_THRESHOLD); A.leaf_threshold = tune("PT_TUNE_LEAF", PT_LEAF_THRESHOLD);
     A.flush_threshold = tune("PT_TUNE_FLUSH", sharded ? 0u : PT_FLUSH_THRESHOLD);   // sharded frames are too small to profit from a second pass
-    A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES); A.drop_cont = tune("PT_TUNE_DROPCONT", 0u); A.adopt = tune("PT_TUNE_ADOPT", 0u);
+    A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES);
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
     int want_slots = int(tune("PT_TUNE_SLOTS", sharded && nf == 1u ? 8u : PT_FRAME_SLOTS));   // small sharded frames need more of them in flight
     if (want_slots < 1) want_slots = 1;
@@ -166,7 +166,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     PT_HIP(ctx, sl.flags.ensure(A.cont_passes ? size_t(A.pool_capacity) * 2u : 4u));
     {   // the resolve pass re-primes the slot; prime explicitly only when the buffer or the frame shape changed
         const size_t n_samples = size_t(A.num_batches) * 64u;
-        A.prime = (sl.primed_ptr != (const void*)sl.samples.ptr || sl.primed_samples != n_samples || stats || tune("PT_TUNE_FOLD", 1u) == 0u) ? 1u : 0u;
+        A.prime = (sl.primed_ptr != (const void*)sl.samples.ptr || sl.primed_samples != n_samples || stats) ? 1u : 0u;
         sl.primed_ptr = sl.samples.ptr; sl.primed_samples = n_samples;
     }
     A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr;

@@ -80,8 +80,8 @@ struct RenderArgs {
     unsigned long long* wave_times;   // STATS diagnostics: 8 words per wave (begin, queue-empty, end ticks @100 MHz, loop counts)
     uint32_t  total_items, chunk_items;   // logical items (64*64*perm_cols) and items per queue claim
     uint32_t  num_batches, perm_cols;     // real (tile,sample) batches; columns of the 64-row batch transpose
-    // path pool: 64 B records (o, d, T, rad, key, item, bounce) donated by sparse wavefronts and adopted by
-    // dense / empty ones within the launch; what is left over is the input of the next pass
+    // path pool: 64 B records (o, d, T, rad, key, item, bounce) donated by sparse wavefronts once the queue is dry;
+    // they are the input of the continuation pass (off by default: PT_FLUSH_THRESHOLD 0)
     float4*   pool; uint32_t* pool_flags; uint32_t* pool_ctrl;      // ctrl: [0] reserved tail, [1] claimed head
     const float4* in_pool; const uint32_t* in_ctrl;                  // previous pass's pool (continuation passes)
     uint32_t  pool_capacity, flush_threshold, cont_passes;
@@ -90,8 +90,6 @@ struct RenderArgs {
     FrameParams frames[PT_MAX_BATCH]; float4* outs[PT_MAX_BATCH];
     uint32_t  num_frames, batches_per_frame;
     uint32_t  prime;            // 1: launch_trace must zero the control block and prefill the samples itself
-    uint32_t  adopt;            // 1: dense / empty wavefronts adopt donated paths within the launch; 0: donations wait for the next pass
-    uint32_t  drop_cont;        // timing experiments only: discard flushed paths (wrong image)
 };
 
 hipError_t launch_render(const RenderArgs& args, int kmode, bool stats, hipStream_t stream);

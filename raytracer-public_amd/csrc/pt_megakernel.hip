@@ -68,12 +68,10 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
     const uint32_t total_items = CONT ? in_count : A.total_items;
     const bool pool_on = A.flush_threshold != 0u;
     // per-frame parameters are read through the kernarg segment (per-lane index: lanes of one refill may straddle two frames)
-    const FrameParams* const frames = (const FrameParams*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(RenderArgs, frames));     // wave-uniform: this pass donates / adopts through A.pool
+    const FrameParams* const frames = (const FrameParams*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(RenderArgs, frames));
     const uint32_t chunk_items = CONT ? 64u : A.chunk_items;
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: this wave's private item range
     bool queue_empty = false;                 // wave-uniform
-    bool donated = false;                     // wave-uniform: this wavefront handed its paths over and is leaving
-    uint32_t loop_count = 0;
 
     Lane S;
     uint32_t phase = kPhaseIdle;
@@ -191,7 +189,6 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every record store has left before its flag is set
                 if (stored) __hip_atomic_store(&A.pool_flags[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                donated = true;
             }
         }
         // ------------------------------------------------------------------ refill IDLE lanes
@@ -255,60 +252,11 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                 if (STATS) cy_fill += __builtin_amdgcn_s_memtime() - cy_mark;
             }
         }
-        // ------------------------------------------------------------------ adopt donated paths
-        // Once the item queue is dry, a wavefront that is empty or still dense fills its idle lanes from
-        // the pool; a sparse one (0 < live < flush_threshold) is a donor and does not adopt.
-        bool pool_drained = true;
-        ++loop_count;
-        if (pool_on && A.adopt != 0u && queue_empty && !donated && ((loop_count & 15u) == 0u || __ballot(phase == kPhaseTrav) == 0ull)) {
-            const unsigned long long m_idle = __ballot(phase == kPhaseIdle);
-            const uint32_t live = 64u - (uint32_t)__popcll(m_idle);
-            const unsigned long long m_trav2 = __ballot(phase == kPhaseTrav);
-            const bool donor = live != 0u && live < A.flush_threshold;
-            if (!donor && ((uint32_t)__popcll(m_idle) >= 16u || m_trav2 == 0ull)) {
-                const uint32_t want = (uint32_t)__popcll(m_idle);
-                uint32_t start = 0, take = 0;
-                if (lane == 0) {
-                    for (int attempt = 0; attempt < 4 && take == 0u; ++attempt) {
-                        const uint32_t tail = min(__hip_atomic_load(&A.pool_ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), A.pool_capacity);
-                        const uint32_t head = __hip_atomic_load(&A.pool_ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (tail <= head) break;
-                        if (live == 0u && tail - head < 32u) break;      // an empty wavefront only starts over with a dense batch
-                        const uint32_t n = min(tail - head, want);
-                        if (atomicCAS(&A.pool_ctrl[1], head, head + n) == head) { start = head; take = n; }
-                    }
-                }
-                start = __builtin_amdgcn_readfirstlane(start); take = __builtin_amdgcn_readfirstlane(take);
-                if (take != 0u) {
-                    pool_drained = false;
-                    const uint32_t rank = (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull));
-                    const bool mine = phase == kPhaseIdle && rank < take;
-                    const uint32_t idx = start + (mine ? rank : 0u);
-                    // the slot is reserved, its donor publishes the flag right after writing: bounded wait
-                    uint32_t spins = 0;
-                    while (mine && __hip_atomic_load(&A.pool_flags[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && spins < (1u << 22)) { __builtin_amdgcn_s_sleep(2); ++spins; }
-                    if (mine) {
-                        // sc1 loads (they bypass this CU's L1), issued only after the lane's own flag poll matched
-                        const uint32_t* rec = (const uint32_t*)(A.pool + (size_t)idx * 4);
-                        uint32_t w[15];
-#pragma unroll
-                        for (int k = 0; k < 15; ++k) w[k] = __hip_atomic_load(rec + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        S.o = f3(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]));
-                        S.d = f3(__uint_as_float(w[3]), __uint_as_float(w[4]), __uint_as_float(w[5])); S.inv = safe_inv(S.d);
-                        S.T = f3(__uint_as_float(w[6]), __uint_as_float(w[7]), __uint_as_float(w[8]));
-                        S.rad = f3(__uint_as_float(w[9]), __uint_as_float(w[10]), __uint_as_float(w[11]));
-                        S.key = w[12]; S.item = w[13]; S.bounce = w[14];
-                        if (STATS) ++c_closest;
-                        phase = begin_ray() ? kPhaseTrav : kPhaseDone;
-                    }
-                }
-            } else if (donor) pool_drained = false;
-        }
         // ------------------------------------------------------------------ exit / idle-spin
         const unsigned long long m_trav = __ballot(phase == kPhaseTrav);
         if (m_trav == 0ull) {
             const unsigned long long m_done = __ballot(phase == kPhaseDone);
-            if (m_done == 0ull && queue_empty && pool_drained) break;   // leftovers in the pool go to the next pass
+            if (m_done == 0ull && queue_empty) break;    // donated paths are picked up by the continuation pass
             continue;
         }
         // ------------------------------------------------------------------ one traversal step
@@ -510,7 +458,7 @@ hipError_t launch_trace(const RenderArgs& A0, bool stats, uint32_t grid_blocks, 
         e = hipMemsetAsync(A0.pool_flags, 0, (size_t)A0.pool_capacity * 2u * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
     }
-    // pass 0: pixel-samples; sparse wavefronts donate into pool A, dense / empty ones adopt from it
+    // pass 0: pixel-samples; with a flush threshold, sparse wavefronts donate their paths into pool A
     A.queue = ctrl; A.pool = pool_a; A.pool_flags = flags_a; A.pool_ctrl = ctrl + 4;
     A.flush_threshold = passes > 0u ? A0.flush_threshold : 0u;
     if (k0) { e = hipEventRecord(k0, stream); if (e != hipSuccess) return e; }
@@ -518,7 +466,7 @@ hipError_t launch_trace(const RenderArgs& A0, bool stats, uint32_t grid_blocks, 
     else       hipLaunchKernelGGL((trace_paths_kernel<false, false>), dim3(grid_blocks), dim3(PT_MEGA_BLOCK), 0, stream, A);
     e = hipGetLastError(); if (e != hipSuccess) return e;
     // continuation passes pick up what is left in the previous pool; the last one never donates
-    for (uint32_t pass = 1; pass <= passes && !A0.drop_cont; ++pass) {
+    for (uint32_t pass = 1; pass <= passes; ++pass) {
         const bool odd = (pass & 1u) != 0u;
         A.queue = ctrl + pass;
         A.in_pool = odd ? pool_a : pool_b; A.in_ctrl = ctrl + (odd ? 4 : 6);
