@@ -439,8 +439,8 @@ bool dragon_class(uint32_t seed, uint32_t num_tris, float* out, std::string& err
     return true;
 }
 
-// Sponza-class: an atrium seen from inside -- floor, ceiling, four walls, two colonnades of
-// fluted columns (long thin triangles) and hanging wavy drapes.  Every camera ray hits.
+// Sponza-class: an atrium seen from inside -- floor, four walls, a roof open along the middle, two
+// colonnades of fluted columns (long thin triangles) and hanging wavy drapes.  Nearly every camera ray hits.
 bool sponza_class(uint32_t seed, uint32_t num_tris, float* out, std::string& err) {
     if (num_tris < 12000) { err = "sponza-class scene needs at least 12000 triangles"; return false; }
     TriList tl{out, num_tris};
@@ -500,10 +500,19 @@ bool sponza_class(uint32_t seed, uint32_t num_tris, float* out, std::string& err
     for (uint32_t pass = 0; pass < 2; ++pass) {
         const double y = pass ? Y : -Y;
         for (uint32_t i = 0; i < gx; ++i) for (uint32_t j = 0; j < gz; ++j) {
+            // the roof is open along the middle of the hall (an atrium): the ceiling grid covers two side
+            // strips, columns j < gz/2 the one at -z, the others the one at +z
+            const uint32_t half = gz / 2;
             auto P = [&](uint32_t ii, uint32_t jj) {
                 const double u = double(ii) / gx, v = double(jj) / gz;
-                const double h = pass ? 0.06 * std::sin(u * 40) * std::sin(v * 9) : 0.01 * (value_noise(u, v, 64, 32, 9, seed) - 0.5);
-                return D3{-X + 2 * X * u, y + h, -Z + 2 * Z * v};
+                if (!pass) {
+                    const double h = 0.01 * (value_noise(u, v, 64, 32, 9, seed) - 0.5);
+                    return D3{-X + 2 * X * u, y + h, -Z + 2 * Z * v};
+                }
+                const bool left = j < half;
+                const double w = left ? double(jj) / half : double(jj - half) / (gz - half);   // 0..1 across the strip
+                const double z = left ? (-Z + 0.5 * Z * w) : (0.5 * Z + 0.5 * Z * w);
+                return D3{-X + 2 * X * u, y + 0.06 * std::sin(u * 40) * std::sin(w * 9), z};
             };
             if (pass) quad(P(i, j), P(i + 1, j), P(i + 1, j + 1), P(i, j + 1));
             else      quad(P(i, j), P(i, j + 1), P(i + 1, j + 1), P(i + 1, j));
