@@ -240,7 +240,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # written from a rocprofv3 --pmc pass
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("bytes_per_launch_n%d" % world)
+                per_frame = json.load(open(pmc)).get("bytes_per_launch_n%d" % world)     # measured per frame of work
+                traffic = int(per_frame * (args.steps / max(len(kernel_ms), 1))) if per_frame else None
             except Exception:
                 traffic = None
         out = {
