@@ -105,6 +105,10 @@ class PathTracer {
   setCameraQuaternion(x, y, z, w) { this.cameraQuaternion = [x, y, z, w]; } // :828
   setFrameCount(frameCount) { this.frameCount = frameCount; }               // :832
 
+  // queue `n` (1..8) consecutive render() calls into one persistent GPU launch; read-backs flush a partial batch
+  setBatch(n) { native().setBatch(this.device, n); }
+  flush() { native().flush(this.device); }
+
   // ---- results (the reference presents to a canvas; a Node host reads them back) ----
   readRadiance() { return native().readRadiance(this.device, this.canvas.width, this.canvas.height); }
   readRGBA8() { return native().readRGBA8(this.device, this.canvas.width, this.canvas.height); }      // outputTex equivalent, :163-172

@@ -9,7 +9,7 @@
 // of the same triangle budget stands in -- the log says so.
 //
 //   node raytracer-public_amd/js/main.js [--frames N] [--width W --height H] [--mode 0|1|2]
-//        [--spp S --bounces B --seed K] [--glb path] [--tris N] [--out frame.ppm] [--dump data/BVH2.bin]
+//        [--spp S --bounces B --seed K] [--glb path] [--tris N] [--batch F] [--out frame.ppm] [--dump data/BVH2.bin]
 "use strict";
 const fs = require("fs");
 const path = require("path");
@@ -51,6 +51,8 @@ async function main() {
 
   // ---------- Render Loop ----------
   const frames = Number(arg("frames", 30));
+  const batch = Number(arg("batch", 1));                      // >1: frames are traced in batches by one launch each
+  if (batch > 1) pathTracer.setBatch(batch);
   let frameIndex = 0;
   await pathTracer.render(); pathTracer.synchronize();        // warm-up (first-touch allocations)
   const t0 = Date.now();

@@ -297,6 +297,18 @@ static napi_value fn_render(napi_env env, napi_callback_info info) {          /*
     return NULL;
 }
 
+static napi_value fn_set_batch(napi_env env, napi_callback_info info) {       /* frames per persistent launch (1..8) */
+    napi_value argv[2]; if (!get_args(env, info, 2, argv)) return NULL;
+    PtContext* ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    PT_CALL(ctx, pt_set_batch(ctx, get_u32(env, argv[1])), "pt_set_batch");
+    return NULL;
+}
+static napi_value fn_flush(napi_env env, napi_callback_info info) {
+    napi_value argv[1]; if (!get_args(env, info, 1, argv)) return NULL;
+    PtContext* ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    PT_CALL(ctx, pt_flush(ctx), "pt_flush");
+    return NULL;
+}
 static napi_value fn_last_ms(napi_env env, napi_callback_info info) {
     napi_value argv[1]; if (!get_args(env, info, 1, argv)) return NULL;
     PtContext* ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
@@ -348,7 +360,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"writeU32File", fn_write_u32}, {"readU32File", fn_read_u32}, {"proceduralScene", fn_procedural},
         {"setTriangles", fn_set_triangles}, {"buildBVH", fn_build_bvh}, {"readBVH2", fn_read_bvh2}, {"readBVH4", fn_read_bvh4},
         {"setBVH4", fn_set_bvh4}, {"setBVH2", fn_set_bvh2}, {"setSpheres", fn_set_spheres}, {"sceneInfo", fn_scene_info},
-        {"render", fn_render}, {"lastRenderMs", fn_last_ms}, {"synchronize", fn_sync}, {"getStats", fn_stats},
+        {"render", fn_render}, {"setBatch", fn_set_batch}, {"flush", fn_flush}, {"lastRenderMs", fn_last_ms}, {"synchronize", fn_sync}, {"getStats", fn_stats},
         {"readRadiance", fn_read_radiance}, {"readRGBA8", fn_read_rgba8}, {"readTonemapped", fn_read_tonemapped},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
