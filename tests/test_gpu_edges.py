@@ -154,3 +154,28 @@ def test_bench_two_ranks_gloo_rehearsal_verifies_gathered_frame():
     line = [l for l in out.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["verified"] is True and res["value"] > 0 and res["scaling"] == "strong"
+
+
+def test_prebuilt_bvh_files_roundtrip(rt, orc, gpu_ctx, tmp_path):
+    """configs C2/C3 name data/BVH2.bin and data/BVH4_wide.bin: dump, reload into a fresh context, render the same."""
+    tris = rt.procedural_scene(0, 20000)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    bvh2, bvh4 = gpu_ctx.read_bvh2(), gpu_ctx.read_bvh4()
+    p2, pw = str(tmp_path / "BVH2.bin"), str(tmp_path / "BVH4_wide.bin")
+    rt.write_u32_file(p2, bvh2)
+    rt.write_u32_file(pw, rt.bvh2_to_bvh4_wide(rt.read_u32_file(p2)))
+    gpu_ctx.render(gpu_ctx.make_params(160, 90, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3)); want = gpu_ctx.read_radiance().copy()
+    fresh = rt.Context(0)
+    fresh.set_triangles(tris)
+    fresh.set_bvh2(rt.read_u32_file(p2))                       # collapse on load, like buildBVH after its read-back
+    assert np.array_equal(fresh.read_bvh4(), bvh4) and np.array_equal(fresh.read_bvh2(), bvh2)
+    fresh.render(fresh.make_params(160, 90, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3))
+    assert same_bits(fresh.read_radiance(), want)
+    fresh.set_bvh4(rt.read_u32_file(pw))                       # the offline converter's output is a valid BVH input as well
+    fresh.render(fresh.make_params(160, 90, mode=rt.PT_MODE_REFERENCE)); a = fresh.read_radiance().copy()
+    gpu_ctx.render(gpu_ctx.make_params(160, 90, mode=rt.PT_MODE_REFERENCE)); b = gpu_ctx.read_radiance()
+    assert ((a.view(np.uint32) != b.view(np.uint32)).any(axis=2)).mean() < 1e-3
+    with pytest.raises(rt.PtError):
+        fresh.set_bvh2(bvh2[:-5])                              # truncated file
+    fresh.close()
