@@ -191,7 +191,8 @@ int pt_tile_layout(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t
 int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats);
 /* Render tile-sharded frames straight into a caller-owned device buffer (e.g. a torch tensor
  * that is then handed to the RCCL gather) instead of the context's own compact buffer.
- * device_ptr = NULL restores the internal buffer.  `floats` is the buffer's capacity. */
+ * device_ptr = NULL restores the internal buffer.  `floats` is the buffer's capacity.  The buffer that is
+ * current when a frame is submitted is that frame's target; it must outlive the frame's launch (pt_flush). */
 int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
 /* Rank 0: scatter `tile_count` gathered compact buffers (device memory, concatenated in rank
  * order, each padded to `stride_floats`) into the context's full-frame radiance buffer. */
