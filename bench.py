@@ -77,8 +77,8 @@ def cpu_baseline_node(tris, bvh4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
@@ -126,7 +126,7 @@ def main():
     # launch (pt_set_batch), which amortises the sparse tail of a frame -- essential for the small per-GPU
     # shares of a sharded run.  The RCCL gather then moves one batch at a time (fewer, larger collectives).
     batch = int(os.environ.get("PT_BENCH_BATCH", "0")) or args.steps // 8     # short runs: smaller batches, shorter fill / drain
-    batch = max(1, min(8, batch))
+    batch = max(1, min(32, batch))   # 32 = pt_set_batch's maximum
     ctx.set_batch(1)
     if sharded:
         stride = max(rt.tile_layout(width, height, r, world)[1] for r in range(world))

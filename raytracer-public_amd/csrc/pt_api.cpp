@@ -148,27 +148,41 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     A.flush_threshold = tune("PT_TUNE_FLUSH", sharded ? 0u : PT_FLUSH_THRESHOLD);   // sharded frames are too small to profit from a second pass
     A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES);
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
-    int want_slots = int(tune("PT_TUNE_SLOTS", sharded && nf == 1u ? 8u : PT_FRAME_SLOTS));   // small sharded frames need more of them in flight
+    // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
+    // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small
+    // sharded launches need several in flight to fill the chip.  Measured: tools/tune13.sh, tools/tune14.sh.
+    const uint32_t work8 = nf * 8u / (count ? count : 1u);      // eighths of a whole frame
+    int want_slots = int(tune("PT_TUNE_SLOTS", work8 >= 64u ? 2u : (work8 >= 16u ? PT_FRAME_SLOTS : (work8 >= 8u ? (sharded ? 4u : PT_FRAME_SLOTS) : (sharded ? 8u : PT_FRAME_SLOTS)))));
     if (want_slots < 1) want_slots = 1;
     if (want_slots > PtContext::kMaxSlots) want_slots = PtContext::kMaxSlots;
     ctx->num_slots = want_slots;
+    // Every slot is sized for a full batch of the current setting (largest grid) and prefilled as a whole the first time
+    // it is needed; from then on the resolve passes keep the buffers primed, whatever prefix a later launch uses.
+    const size_t n_samples = size_t(A.num_batches) * 64u;
+    const size_t cap_samples = std::max(n_samples, size_t(A.batches_per_frame) * 64u * size_t(ctx->batch_size));
+    if (cap_samples > 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: batch too large (more than 2^32 samples per launch)");
+    const uint32_t full_lanes = ptk::megakernel_grid(ctx->num_cus > 0 ? ctx->num_cus : 256) * ptk::megakernel_block();
+    A.pool_capacity = full_lanes * 2u;           // donations can repeat; a full pool just stops donating
+    for (int si = 0; si < (stats ? 1 : want_slots); ++si) {
+        PtContext::FrameSlot& s = ctx->slots[si];
+        if (!s.side) {
+            PT_HIP(ctx, hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
+            PT_HIP(ctx, hipEventCreateWithFlags(&s.resolved, hipEventDisableTiming));
+            PT_HIP(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        }
+        PT_HIP(ctx, s.queue.ensure(16));
+        PT_HIP(ctx, s.samples.ensure(cap_samples));
+        PT_HIP(ctx, s.spill.ensure(size_t(full_lanes) * size_t(64 - PT_SHORT_STACK)));
+        PT_HIP(ctx, s.cont.ensure(A.cont_passes ? size_t(A.pool_capacity) * 4u * 2u : 4u));
+        PT_HIP(ctx, s.flags.ensure(A.cont_passes ? size_t(A.pool_capacity) * 2u : 4u));
+        if (s.primed_ptr != (const void*)s.samples.ptr || s.primed_samples < cap_samples) {
+            if (s.used) PT_HIP(ctx, hipStreamWaitEvent(s.side, s.resolved, 0));
+            PT_HIP(ctx, ptk::launch_prime(s.queue.ptr, s.samples.ptr, uint32_t(cap_samples), s.side));
+            s.primed_ptr = s.samples.ptr; s.primed_samples = cap_samples;
+        }
+    }
     PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(want_slots))];
-    if (!sl.side) {
-        PT_HIP(ctx, hipStreamCreateWithFlags(&sl.side, hipStreamNonBlocking));
-        PT_HIP(ctx, hipEventCreateWithFlags(&sl.resolved, hipEventDisableTiming));
-        PT_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-    }
-    PT_HIP(ctx, sl.queue.ensure(16));
-    PT_HIP(ctx, sl.samples.ensure(size_t(A.num_batches) * 64u));
-    PT_HIP(ctx, sl.spill.ensure(size_t(grid_lanes) * size_t(64 - PT_SHORT_STACK)));
-    A.pool_capacity = grid_lanes * 2u;           // donations can repeat; a full pool just stops donating
-    PT_HIP(ctx, sl.cont.ensure(A.cont_passes ? size_t(A.pool_capacity) * 4u * 2u : 4u));
-    PT_HIP(ctx, sl.flags.ensure(A.cont_passes ? size_t(A.pool_capacity) * 2u : 4u));
-    {   // the resolve pass re-primes the slot; prime explicitly only when the buffer or the frame shape changed
-        const size_t n_samples = size_t(A.num_batches) * 64u;
-        A.prime = (sl.primed_ptr != (const void*)sl.samples.ptr || sl.primed_samples != n_samples || stats) ? 1u : 0u;
-        sl.primed_ptr = sl.samples.ptr; sl.primed_samples = n_samples;
-    }
+    A.prime = stats ? 1u : 0u;                   // instrumented launches start from a freshly primed prefix
     A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr;
     if (stats) {
         const uint32_t waves = grid_lanes / 64u;
@@ -602,7 +616,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
 int pt_set_batch(PtContext* ctx, uint32_t frames_per_launch) {
     if (int rc = bind(ctx)) return rc;
     if (int rc = flush_pending(ctx)) return rc;
-    if (frames_per_launch < 1u || frames_per_launch > PT_MAX_BATCH) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_batch: 1..8 frames per launch");
+    if (frames_per_launch < 1u || frames_per_launch > PT_MAX_BATCH) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_batch: 1..32 frames per launch");
     ctx->batch_size = frames_per_launch;
     return PT_OK;
 }

@@ -38,7 +38,7 @@
 
 namespace ptk {
 
-#define PT_MAX_BATCH 8
+#define PT_MAX_BATCH 32     // frames per persistent launch (FrameParams + out pointer: 56 B of kernarg each)
 // Per-frame part of the UBO for a batched launch (several consecutive frames traced by one persistent launch).
 struct FrameParams {
     float cam[3]; float focal;
@@ -95,6 +95,7 @@ struct RenderArgs {
 hipError_t launch_render(const RenderArgs& args, int kmode, bool stats, hipStream_t stream);
 // k0/k1 (optional): events recorded immediately around the trace_paths_kernel launches
 hipError_t launch_trace(const RenderArgs& args, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1);
+hipError_t launch_prime(uint32_t* queue, float4* samples, uint32_t n_samples, hipStream_t stream);   // first use of a frame slot
 hipError_t launch_resolve(const RenderArgs& args, hipStream_t stream);
 uint32_t megakernel_grid(int num_cus);
 uint32_t megakernel_block();

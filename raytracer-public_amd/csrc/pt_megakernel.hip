@@ -491,6 +491,13 @@ hipError_t launch_resolve(const RenderArgs& A, hipStream_t stream) {
     return hipGetLastError();
 }
 
+hipError_t launch_prime(uint32_t* queue, float4* samples, uint32_t n_samples, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(queue, 0, 16 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    if (n_samples) hipLaunchKernelGGL(prefill_samples_kernel, dim3(2048), dim3(256), 0, stream, samples, n_samples);
+    return hipGetLastError();
+}
+
 uint32_t megakernel_grid(int num_cus) { return (uint32_t)num_cus * PT_MEGA_WAVES_PER_SIMD * (256 / PT_MEGA_BLOCK); }
 uint32_t megakernel_block() { return PT_MEGA_BLOCK; }
 

@@ -276,6 +276,26 @@ def test_batched_launch_equals_frame_by_frame(rt, gpu_ctx):
     assert same_bits(got, ref)
 
 
+def test_largest_batch_accumulates_like_single_launches(rt, gpu_ctx):
+    """32 frames (the pt_set_batch maximum) in one launch, accumulated: the running sum is the one 32 launches give."""
+    tris = rt.procedural_scene(0, 12000)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    w, h = 96, 64
+    def run(batch):
+        gpu_ctx.render(gpu_ctx.make_params(w, h, mode=rt.PT_MODE_REFERENCE))  # ends any accumulating sequence
+        gpu_ctx.set_batch(batch)
+        for f in range(32):
+            gpu_ctx.render(gpu_ctx.make_params(w, h, mode=rt.PT_MODE_PATH, spp=1, max_bounces=4, seed=9, frame=f, accumulate=True))
+        out = gpu_ctx.read_radiance().copy()
+        gpu_ctx.set_batch(1)
+        return out
+    a, b = run(1), run(32)
+    assert same_bits(a, b)
+    with pytest.raises(rt.PtError):
+        gpu_ctx.set_batch(33)
+
+
 def test_error_paths(rt, gpu_ctx):
     fresh = rt.Context(0)
     with pytest.raises(rt.PtError) as e:
