@@ -125,7 +125,8 @@ def main():
     # Frames are submitted in batches: the library traces `batch` consecutive frames with one persistent
     # launch (pt_set_batch), which amortises the sparse tail of a frame -- essential for the small per-GPU
     # shares of a sharded run.  The RCCL gather then moves one batch at a time (fewer, larger collectives).
-    batch = int(os.environ.get("PT_BENCH_BATCH", "0")) or args.steps // 8     # short runs: smaller batches, shorter fill / drain
+    # At least two launches per timed region so that consecutive launches overlap (measured: tools/tune16.sh).
+    batch = int(os.environ.get("PT_BENCH_BATCH", "0")) or (args.steps + 1) // 2
     batch = max(1, min(32, batch))   # 32 = pt_set_batch's maximum
     ctx.set_batch(1)
     if sharded:
@@ -133,6 +134,7 @@ def main():
         compact = [torch.zeros(batch, stride, dtype=torch.float32, device="cuda") for _ in range(2)]
         gathered = [torch.zeros(world, batch, stride, dtype=torch.float32, device="cuda") for _ in range(2)] if rank == 0 else [None, None]
         host_stage = backend != "nccl"   # rehearsal path (gloo): stage through host memory
+        torch.cuda.synchronize()         # the zero fills ran on torch's default stream; everything below uses the context's
 
     # exact traversal counters of this rank's share of the frame (deterministic, same every step)
     with torch.cuda.stream(stream):
