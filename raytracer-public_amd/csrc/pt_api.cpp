@@ -52,6 +52,9 @@ struct PtContext {
     DevBuf<uint32_t> d_bvh2, d_bvh4; // reference layouts
     DevBuf<uint4> d_wide;            // 4 x uint4 per internal node
     DevBuf<uint32_t> d_morton, d_triidx, d_parent, d_flags;
+    // device-side scene build (pt_build.hip): scratch kept for rebuilds
+    DevBuf<unsigned long long> d_bounds; DevBuf<uint32_t> d_counters, d_code_tmp, d_index_tmp, d_node2, d_subtree, d_ids, d_bnd;
+    DevBuf<uint4> d_child_pos; DevBuf<unsigned char> d_build_temp; uint32_t* h_word = nullptr;
     DevBuf<float4> d_spheres; uint32_t num_spheres = 0;
 
     // frame
@@ -262,6 +265,9 @@ void pt_destroy(PtContext* ctx) {
     ctx->d_out.release(); ctx->d_accum.release(); ctx->d_compact.release(); ctx->d_compact_accum.release();
     ctx->d_tiles.release(); ctx->d_u32tmp.release(); ctx->d_stats.release();
     ctx->d_wave_times.release();
+    ctx->d_bounds.release(); ctx->d_counters.release(); ctx->d_code_tmp.release(); ctx->d_index_tmp.release(); ctx->d_node2.release();
+    ctx->d_subtree.release(); ctx->d_ids.release(); ctx->d_bnd.release(); ctx->d_child_pos.release(); ctx->d_build_temp.release();
+    if (ctx->h_word) (void)hipHostFree(ctx->h_word);
     for (auto& sl : ctx->slots) {
         sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.cont.release(); sl.flags.release();
         if (sl.resolved) (void)hipEventDestroy(sl.resolved);
@@ -372,11 +378,9 @@ int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris) {
     if (num_tris >= 0x7fffffffu) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_triangles: too many triangles for the 31-bit leaf index");
     PT_HIP(ctx, ctx->d_tris9.ensure(size_t(num_tris) * 9));
     PT_HIP(ctx, ctx->d_trirec.ensure(size_t(num_tris) * 3 + 4));   // +64 B: the megakernel's unified 64 B fetch over-reads the last record
-    std::vector<pt::TriRecord> rec(num_tris);
-    pt::build_tri_records(tris, num_tris, rec.data());
     if (num_tris) {
         PT_HIP(ctx, hipMemcpyAsync(ctx->d_tris9.ptr, tris, size_t(num_tris) * 36, hipMemcpyHostToDevice, ctx->stream));
-        PT_HIP(ctx, hipMemcpyAsync(ctx->d_trirec.ptr, rec.data(), size_t(num_tris) * sizeof(pt::TriRecord), hipMemcpyHostToDevice, ctx->stream));
+        PT_HIP(ctx, ptk::launch_tri_records(ctx->d_tris9.ptr, num_tris, ctx->d_trirec.ptr, ctx->stream));   // 48 B records, DESIGN.md section 5
     }
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->num_tris = num_tris;
@@ -457,18 +461,59 @@ int pt_build_bvh(PtContext* ctx) {
         if (int rc = pt_build_lbvh2(ctx, nullptr, nullptr)) return rc;
         return upload_wide(ctx, &zero, 1);
     }
-    std::vector<float> tris(size_t(n) * 9);
-    PT_HIP(ctx, hipMemcpy(tris.data(), ctx->d_tris9.ptr, size_t(n) * 36, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> morton(n), tri_index(n);
-    pt::morton_codes_sorted(tris.data(), n, morton.data(), tri_index.data());
-    if (int rc = pt_build_lbvh2(ctx, morton.data(), tri_index.data())) return rc;
-    uint64_t bytes = 0; pt_compute_bvh2_sizing(n, nullptr, &bytes);
-    std::vector<uint32_t> bvh2(bytes / 4);
-    if (int rc = pt_read_bvh2(ctx, bvh2.data(), bytes)) return rc;       // PathTracer.js:731
-    std::vector<uint32_t> b4; std::string err;
-    if (!pt::collapse_to_bvh4(bvh2.data(), n, b4, err)) return fail(ctx, PT_ERR_BAD_BVH, err);   // :735
+    // Every step of PathTracer.buildBVH (:671-749) on the device, nothing crosses PCIe but a few counters:
+    // Morton codes + stable radix sort (:411-481), LBVH2 kernels (BVHBuilder.wgsl), collapse to BVH4 (:506-667), device layouts.
+    uint32_t nn2 = 0; uint64_t bytes2 = 0;
+    pt_compute_bvh2_sizing(n, &nn2, &bytes2);
+    PT_HIP(ctx, ctx->d_bvh2.ensure(bytes2 / 4));
+    PT_HIP(ctx, ctx->d_morton.ensure(n)); PT_HIP(ctx, ctx->d_triidx.ensure(n));
+    PT_HIP(ctx, ctx->d_parent.ensure(nn2)); PT_HIP(ctx, ctx->d_flags.ensure(n > 1 ? n - 1 : 1));
+    PT_HIP(ctx, ctx->d_bounds.ensure(6)); PT_HIP(ctx, ctx->d_counters.ensure(ptk::kBuildCounters));
+    PT_HIP(ctx, ctx->d_code_tmp.ensure(n)); PT_HIP(ctx, ctx->d_index_tmp.ensure(n));
+    PT_HIP(ctx, ctx->d_node2.ensure(nn2)); PT_HIP(ctx, ctx->d_child_pos.ensure(nn2)); PT_HIP(ctx, ctx->d_subtree.ensure(nn2));
+    PT_HIP(ctx, ctx->d_ids.ensure(nn2)); PT_HIP(ctx, ctx->d_bnd.ensure(size_t(nn2) * 3));
+    const size_t temp_bytes = ptk::build_temp_bytes(n);
+    PT_HIP(ctx, ctx->d_build_temp.ensure(temp_bytes));
+    if (!ctx->h_word) PT_HIP(ctx, hipHostMalloc((void**)&ctx->h_word, 64, hipHostMallocDefault));
+    PT_HIP(ctx, ctx->d_bvh4.ensure(1 + size_t(nn2) * 8));      // M <= 2N-1 nodes
+    ptk::BuildBuffers B;
+    B.bounds = ctx->d_bounds.ptr; B.counters = ctx->d_counters.ptr; B.code_tmp = ctx->d_code_tmp.ptr; B.index_tmp = ctx->d_index_tmp.ptr;
+    B.morton = ctx->d_morton.ptr; B.tri_index = ctx->d_triidx.ptr; B.temp = ctx->d_build_temp.ptr; B.temp_bytes = temp_bytes;
+    B.node2 = ctx->d_node2.ptr; B.child_pos = ctx->d_child_pos.ptr; B.subtree = ctx->d_subtree.ptr; B.ids = ctx->d_ids.ptr; B.bnd = ctx->d_bnd.ptr;
+    B.host_word = ctx->h_word;
+    ctx->have_bvh = false; ctx->have_bvh2 = false;
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh2.ptr, &nn2, 4, hipMemcpyHostToDevice, ctx->stream));   // BVH2[0] = numNodes2, PathTracer.js:699
+    PT_HIP(ctx, ptk::launch_morton_sort(B, ctx->d_tris9.ptr, n, ctx->stream));
+    PT_HIP(ctx, ptk::launch_lbvh2(ctx->d_bvh2.ptr, ctx->d_tris9.ptr, ctx->d_morton.ptr, ctx->d_triidx.ptr, ctx->d_parent.ptr, ctx->d_flags.ptr, n, ctx->stream));
+    ctx->num_nodes2 = nn2;
+    uint32_t m = 0;
+    {
+        hipError_t e = ptk::collapse_on_device(B, ctx->d_bvh2.ptr, n, ctx->d_bvh4.ptr, &m, ctx->stream);
+        if (e == hipErrorInvalidValue) return fail(ctx, PT_ERR_BAD_BVH, "pt_build_bvh: the LBVH2 is not a tree of 2N-1 nodes");
+        PT_HIP(ctx, e);
+    }
+    ctx->have_bvh2 = true;
+    PT_HIP(ctx, ptk::launch_internal_scan(B, ctx->d_bvh4.ptr, m, ctx->stream));
+    uint32_t tail[2] = {0, 0}, root[8];
+    PT_HIP(ctx, hipMemcpyAsync(&tail[0], ctx->d_ids.ptr + (m - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipMemcpyAsync(&tail[1], ctx->d_subtree.ptr + (m - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipMemcpyAsync(root, ctx->d_bvh4.ptr + 1, 32, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t internal = tail[0] + tail[1];
+    PT_HIP(ctx, ctx->d_wide.ensure(size_t(internal) * 4 + 4));
+    PT_HIP(ctx, ptk::launch_wide_nodes(B, ctx->d_bvh4.ptr, m, ctx->d_wide.ptr, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pt::WideBvh meta;
+    meta.num_nodes4 = m;
+    meta.root_box[0] = root[0]; meta.root_box[1] = root[1]; meta.root_box[2] = root[2];
+    meta.root_degenerate = pt::half_to_float(root[0] & 0xffffu) > pt::half_to_float(root[1] >> 16) || pt::half_to_float(root[0] >> 16) > pt::half_to_float(root[2] & 0xffffu) ||
+                           pt::half_to_float(root[1] & 0xffffu) > pt::half_to_float(root[2] >> 16);
+    meta.root_ref = (root[7] & pt::kLeafFlag) ? (pt::kLeafFlag | (root[7] & 0x7fffffffu)) : 0u;
+    ctx->wide_meta = meta;
+    ctx->num_nodes4 = m;
+    ctx->have_bvh = true;
     ctx->accum_count = 0;
-    return upload_wide(ctx, b4.data(), b4.size());                     // :739-740
+    return PT_OK;
 }
 
 int pt_read_bvh4(PtContext* ctx, uint32_t* dst, uint64_t bytes) {

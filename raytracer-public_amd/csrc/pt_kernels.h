@@ -101,6 +101,25 @@ uint32_t megakernel_grid(int num_cus);
 uint32_t megakernel_block();
 hipError_t launch_lbvh2(uint32_t* bvh2, const float* tris9, const uint32_t* morton, const uint32_t* tri_index,
                         uint32_t* parent, uint32_t* flags, uint32_t num_tris, hipStream_t stream);
+// ---- device-side scene build (pt_build.hip) -------------------------------------------------
+constexpr int kBuildCounters = 256;      // one append counter per BVH4 level (an LBVH2 over 30-bit codes + index bits is < 64 deep)
+struct BuildBuffers {
+    unsigned long long* bounds;          // [6] centroid bounds as order-preserving u64 keys
+    uint32_t* counters;                  // [kBuildCounters]
+    uint32_t *code_tmp, *index_tmp;      // [n] Morton codes / triangle ids before the sort
+    uint32_t *morton, *tri_index;        // [n] after the sort: the inputs of launch_lbvh2
+    void* temp; size_t temp_bytes;       // rocPRIM scratch (build_temp_bytes)
+    uint32_t* node2; uint4* child_pos; uint32_t *subtree, *ids, *bnd;   // [2n-1] per BVH4 node in breadth-first order (bnd: 3 words each)
+    uint32_t* host_word;                 // pinned host word for the per-level counts
+};
+size_t build_temp_bytes(uint32_t num_tris);
+hipError_t launch_tri_records(const float* tris9, uint32_t num_tris, float4* records, hipStream_t stream);
+hipError_t launch_morton_sort(const BuildBuffers& B, const float* tris9, uint32_t num_tris, hipStream_t stream);
+// synchronises the stream once per BVH4 level (the level sizes size the next launch); *num_nodes4 = M on return
+hipError_t collapse_on_device(const BuildBuffers& B, const uint32_t* bvh2, uint32_t num_tris, uint32_t* bvh4, uint32_t* num_nodes4, hipStream_t stream);
+// B.subtree[i] = 1 for internal node id i, B.ids = its exclusive prefix sum (the wide-node index)
+hipError_t launch_internal_scan(const BuildBuffers& B, const uint32_t* bvh4, uint32_t num_nodes4, hipStream_t stream);
+hipError_t launch_wide_nodes(const BuildBuffers& B, const uint32_t* bvh4, uint32_t num_nodes4, uint4* wide, hipStream_t stream);
 hipError_t launch_deinterleave(const float4* gathered, uint64_t stride_px, float4* full, uint32_t width, uint32_t height,
                                uint32_t count, hipStream_t stream);
 hipError_t launch_rgba8(const float4* src, uint32_t* dst, uint32_t n, hipStream_t stream);

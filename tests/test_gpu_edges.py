@@ -114,6 +114,18 @@ def test_full_size_c2_properties(rt, orc, gpu_ctx_full):
     assert np.isfinite(a).all() and a[..., :3].min() >= 0.0
 
 
+def test_full_size_device_build_equals_host_build(rt, gpu_ctx_full):
+    """871,414 triangles: pt_build_bvh (all on the device) against the host entry points that mirror the reference's
+    JavaScript steps (pt_morton_sort = buildMortonAndSort, pt_collapse_lbvh2_to_bvh4 = collapseLBVH2ToBVH4)."""
+    ctx = gpu_ctx_full
+    bvh2, bvh4 = ctx.read_bvh2(), ctx.read_bvh4()
+    morton, tri_index = rt.morton_sort(ctx._tris)
+    leaf_tris = bvh2[1 + 6 * (871414 - 1) + 5::6] & 0x7FFFFFFF              # leaf i holds sorted triangle i
+    assert np.array_equal(leaf_tris, tri_index)
+    want4, n4 = rt.collapse_lbvh2_to_bvh4(bvh2, 871414)
+    assert n4 == bvh4[0] and np.array_equal(bvh4, want4[: 1 + 8 * n4])
+
+
 def test_full_size_c3_bvh4_wide(rt, orc, gpu_ctx_full):
     # config C3's input: BVH4_wide of the same BVH2 (M = 2N-1 nodes): closest hits identical to the collapsed BVH4
     ctx = gpu_ctx_full

@@ -42,14 +42,44 @@ def test_lbvh2_tetra_known_answer(rt, gpu_ctx):
     assert [int(b[1 + 6 * node + 5]) for node in range(3, 7)] == [0x80000003, 0x80000000, 0x80000002, 0x80000001]
 
 
-@pytest.mark.parametrize("n,seed", [(4, 0), (777, 1), (30000, 2)])
+@pytest.mark.parametrize("n,seed", [(1, 9), (2, 8), (3, 7), (4, 0), (5, 6), (64, 5), (65, 4), (777, 1), (30000, 2), (120000, 3)])
 def test_build_bvh_end_to_end(rt, orc, gpu_ctx, n, seed):
+    """pt_build_bvh runs Morton + sort, LBVH2, the collapse and the re-layout on the device: BVH2 and BVH4 equal the oracle's."""
     tris = TETRA if n == 4 else random_soup(n, seed)
     gpu_ctx.set_triangles(tris)
     gpu_ctx.build_bvh()
     bvh2, bvh4 = orc.build_bvh4(tris)
     assert np.array_equal(gpu_ctx.read_bvh2(), bvh2)
     assert np.array_equal(gpu_ctx.read_bvh4(), bvh4)
+
+
+@pytest.mark.parametrize("kind", ["identical", "coplanar", "two_clusters", "tiny", "signed_zero"])
+def test_build_bvh_degenerate_inputs(rt, orc, gpu_ctx, kind):
+    """Equal Morton codes (index tie-break), zero extent on an axis (1e-20 floor), f16-subnormal bounds, -0 coordinates."""
+    rng = np.random.default_rng(3)
+    if kind == "identical":
+        tris = np.tile(np.array([0.1, 0.2, 0.3, 0.4, 0.2, 0.3, 0.1, 0.5, 0.3], np.float32), 300)
+    elif kind == "coplanar":
+        tris = rng.uniform(-1, 1, (500, 3, 3)).astype(np.float32); tris[:, :, 2] = 0.25; tris = tris.reshape(-1)
+    elif kind == "two_clusters":
+        a = rng.uniform(-1e-3, 1e-3, (200, 3, 3)).astype(np.float32) + np.float32(-0.9)
+        b = rng.uniform(-1e-3, 1e-3, (200, 3, 3)).astype(np.float32) + np.float32(0.9)
+        tris = np.concatenate([a, b]).reshape(-1)
+    elif kind == "tiny":
+        tris = rng.uniform(-3e-6, 3e-6, (400, 3, 3)).astype(np.float32).reshape(-1)     # below the f16 normal range
+    else:
+        tris = rng.uniform(-1, 1, (256, 3, 3)).astype(np.float32)
+        tris[::3, :, 0] = np.float32(-0.0); tris[1::3, :, 1] = np.float32(0.0); tris = tris.reshape(-1)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    bvh2, bvh4 = orc.build_bvh4(tris)
+    assert np.array_equal(gpu_ctx.read_bvh2(), bvh2)
+    assert np.array_equal(gpu_ctx.read_bvh4(), bvh4)
+    # the device layouts built from it render like the oracle
+    p = gpu_ctx.make_params(64, 48, (0, 0, 2.5), (0, 0, 0, 1), mode=rt.PT_MODE_REFERENCE)
+    gpu_ctx.render(p)
+    want, _, _ = orc.render(orc.make_params(64, 48, len(tris) // 9, (0, 0, 2.5), (0, 0, 0, 1), mode=orc_mod.MODE_SINGLE), tris, bvh4)
+    assert same_bits(gpu_ctx.read_radiance(), want)
 
 
 CAMS = [((0, 0, 2.5), (0, 0, 0, 1)), ((0.4, 0.3, 1.7), quat_yaw_pitch(0.2, -0.15)), ((0, 0, 0), quat_yaw_pitch(2.0, 0.4))]
