@@ -71,7 +71,7 @@ struct PtContext {
     static constexpr int kMaxSlots = 16;
     FrameSlot slots[kMaxSlots]; int num_slots = 0; uint32_t next_slot = 0;
     // frames queued for one batched launch (pt_set_batch): launched when full or when anything needs their result
-    uint32_t batch_size = 1; uint32_t pending = 0; ptk::RenderArgs pendingA; bool pending_ring = false;
+    uint32_t batch_size = 1; uint32_t pending = 0; ptk::RenderArgs pendingA; bool pending_ring = false; uint32_t pending_rank = 0, pending_count = 1;
     DevBuf<unsigned long long> d_wave_times; uint32_t wave_times_n = 0;
     int num_cus = 0;
     DevBuf<unsigned long long> d_stats;
@@ -573,6 +573,17 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     const bool stats = (p->flags & PT_FLAG_STATS) != 0;
     if (stats && p->mode == PT_MODE_REFERENCE_PACKET) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: no counters in the literal packet mode");
 
+    // A frame joins the open batch only if it has the same shape (resolution, spp, bounces, triangle count, tile share,
+    // accumulation) and runs on the megakernel; anything else launches the open batch FIRST -- before any output buffer
+    // is resized or the tile list is rewritten under the queued frames.
+    if (ctx->pending) {
+        const ptk::RenderArgs& Q = ctx->pendingA;
+        const bool mega = p->mode == PT_MODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute && !stats;
+        const bool same = mega && Q.width == p->width && Q.height == p->height && Q.spp == p->spp && Q.max_bounces == p->max_bounces && Q.num_tris == p->num_tris &&
+                          ctx->pending_rank == p->tile_rank && ctx->pending_count == count && (Q.accum != nullptr) == (p->accumulate != 0);
+        if (!same) { if (int rc = flush_pending(ctx)) return rc; }
+    }
+
     ptk::RenderArgs A; std::memset(&A, 0, sizeof(A));
     A.nodes = ctx->d_wide.ptr; A.tris = ctx->d_trirec.ptr; A.bvh4_ref = ctx->d_bvh4.ptr; A.tris9 = ctx->d_tris9.ptr;
     A.width = p->width; A.height = p->height; A.focal = p->focal; A.aspect = p->aspect;
@@ -641,7 +652,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
                               Q.tiles == A.tiles && Q.num_tiles == A.num_tiles && Q.compact == A.compact && Q.accum == A.accum && !stats;
             if (!same || ctx->pending >= PT_MAX_BATCH) { if (int rc = flush_pending(ctx)) return rc; }
         }
-        if (!ctx->pending) { ctx->pendingA = A; ctx->pending_ring = false; }
+        if (!ctx->pending) { ctx->pendingA = A; ctx->pending_ring = false; ctx->pending_rank = p->tile_rank; ctx->pending_count = count; }
         ctx->pendingA.frames[ctx->pending] = fp; ctx->pendingA.outs[ctx->pending] = A.out;
         ++ctx->pending;
         ctx->timed = false;

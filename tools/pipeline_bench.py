@@ -5,13 +5,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 if os.environ.get("PB_TORCH"):
     import torch
 rt = importlib.import_module("raytracer-public_amd")
-tris = rt.procedural_scene(0, 871414)
+sponza = os.environ.get("PF_SCENE") == "sponza"      # config C4 instead of C2
+tris = rt.procedural_scene(1, 262144) if sponza else rt.procedural_scene(0, 871414)
+cam, quat = ((0.55, -0.05, 0.05), (0.0, 0.6630, 0.0, 0.7486)) if sponza else ((0, 0, 2.5), (0, 0, 0, 1))
 ctx = rt.Context(0)
 if os.environ.get("PB_TORCH") == "2":
     st = torch.cuda.Stream(); ctx.set_stream(st.cuda_stream)
 ctx.set_triangles(tris); ctx.build_bvh()
 tc = int(os.environ.get('PB_TILES', '1'))
-p = ctx.make_params(1920, 1080, mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, tile_rank=0, tile_count=tc)
+p = ctx.make_params(1920, 1080, cam, quat, mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, tile_rank=0, tile_count=tc)
 B = int(os.environ.get('PB_BATCH', '1')); ctx.set_batch(B)
 for _ in range(8 * B): ctx.render(p)
 ctx.synchronize()

@@ -5,9 +5,11 @@ import ctypes as C, importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 rt = importlib.import_module("raytracer-public_amd")
-tris = rt.procedural_scene(0, 871414)
+sponza = os.environ.get("PF_SCENE") == "sponza"      # config C4 instead of C2
+tris = rt.procedural_scene(1, 262144) if sponza else rt.procedural_scene(0, 871414)
+cam, quat = ((0.55, -0.05, 0.05), (0.0, 0.6630, 0.0, 0.7486)) if sponza else ((0, 0, 2.5), (0, 0, 0, 1))
 ctx = rt.Context(0); ctx.set_triangles(tris); ctx.build_bvh()
-p = ctx.make_params(1920, 1080, mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, stats=True)
+p = ctx.make_params(1920, 1080, cam, quat, mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, stats=True)
 ctx.render(p); ctx.render(p)
 print("ms (stats build):", ctx.last_render_ms())
 buf = np.zeros((8192, 16), np.uint64); n = C.c_uint32()
