@@ -20,7 +20,10 @@ ctx.synchronize()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 if os.environ.get("PB_RING"): ctx.timing_begin(n)
 t0 = time.perf_counter()
-for _ in range(n): ctx.render(p)
+vary = bool(os.environ.get("PB_VARY"))        # a new frame index (new sample set) every frame, like a progressive render
+for i in range(n):
+    if vary: p.frame = 1000 + i
+    ctx.render(p)
 ctx.synchronize()
 dt = time.perf_counter() - t0
 if os.environ.get("PB_RING"):
