@@ -79,6 +79,7 @@ struct RenderArgs {
     uint2*    spill;            // deep stack entries: [entry][grid lane]
     unsigned long long* wave_times;   // STATS diagnostics: 8 words per wave (begin, queue-empty, end ticks @100 MHz, loop counts)
     uint32_t  total_items, chunk_items;   // logical items (64*64*perm_cols) and items per queue claim
+    uint32_t  xcd_span;                   // 0: one queue; else items per XCD range (8 cursors at queue[8..15])
     uint32_t  num_batches, perm_cols;     // real (tile,sample) batches; columns of the 64-row batch transpose
     // path pool: 64 B records (o, d, T, rad, key, item, bounce) donated by sparse wavefronts once the queue is dry;
     // they are the input of the continuation pass (off by default: PT_FLUSH_THRESHOLD 0)

@@ -70,6 +70,9 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
     // per-frame parameters are read through the kernarg segment (per-lane index: lanes of one refill may straddle two frames)
     const FrameParams* const frames = (const FrameParams*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(RenderArgs, frames));
     const uint32_t chunk_items = CONT ? 64u : A.chunk_items;
+    // the XCD this wavefront runs on (HW_REG_XCC_ID, bits 3:0) and how many other XCDs' ranges it has moved on to
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
+    uint32_t xcd_hop = 0;
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: this wave's private item range
     bool queue_empty = false;                 // wave-uniform
 
@@ -200,11 +203,27 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                 if (STATS) { ++n_fill; cy_mark = __builtin_amdgcn_s_memtime(); }
                 if (chunk_end - chunk_next < want && chunk_next == chunk_end) {
                     // claim a new chunk (one atomic per wave and chunk)
+                    if (!CONT && A.xcd_span != 0u) {
+                        // XCD-aware queue: the logical item space is cut into 8 contiguous ranges, one cursor each; a wavefront
+                        // works through the range of the XCD it runs on (its neighbours in the queue order are then traced by
+                        // wavefronts that share its L2) and moves on to the next XCD's range when its own has run dry
+                        for (;;) {
+                            const uint32_t qi = (xcc + xcd_hop) & 7u;
+                            const uint32_t q_begin = qi * A.xcd_span;
+                            const uint32_t q_end = min(q_begin + A.xcd_span, total_items);
+                            uint32_t start = 0;
+                            if (lane == 0) start = atomicAdd(A.queue + 8 + qi, chunk_items);
+                            start = __builtin_amdgcn_readfirstlane(start);
+                            if (q_begin < q_end && start < q_end - q_begin) { chunk_next = q_begin + start; chunk_end = min(chunk_next + chunk_items, q_end); break; }
+                            if (++xcd_hop == 8u) { queue_empty = true; if (STATS) { t_qempty = wall_clock64(); n_iter_q = n_iter; lanes_sum_q = lanes_sum; } break; }
+                        }
+                    } else {
                     uint32_t start = 0;
                     if (lane == 0) start = atomicAdd(A.queue, chunk_items);
                     start = __builtin_amdgcn_readfirstlane(start);
                     if (start >= total_items) { queue_empty = true; if (STATS) { t_qempty = wall_clock64(); n_iter_q = n_iter; lanes_sum_q = lanes_sum; } }
                     else { chunk_next = start; chunk_end = min(start + chunk_items, total_items); }
+                    }
                 }
                 if (!queue_empty) {
                     const uint32_t rank = (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull));
@@ -424,7 +443,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
         const float inv = 1.0f / count;
         outs[fid][out_index] = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, 1.0f);
     }
-    if (idx == 0u) { for (int k = 0; k < 8; ++k) A.queue[k] = 0u; }   // and its control block rewound
+    if (idx == 0u) { for (int k = 0; k < 16; ++k) A.queue[k] = 0u; }   // and its control block rewound
 }
 
 // every sample starts as the camera-ray miss value 0 + 1 * 0.01 (renderer.wgsl:410)
