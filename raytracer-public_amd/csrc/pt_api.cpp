@@ -144,8 +144,21 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     A.num_frames = nf;
     A.batches_per_frame = A.num_tiles * A.spp;
     A.num_batches = A.batches_per_frame * nf;
-    A.perm_cols = (A.num_batches + 63u) / 64u;
-    A.total_items = A.perm_cols * 64u * 64u;
+    // Rows of the batch transposition (the order in which the queue walks the (frame, tile, sample) batches).  Rows that are a
+    // multiple or a divisor of the frame count keep the frames of a launch aligned: all rows are at the same image position at
+    // the same time, so the frames share the BVH nodes they pull through L2.  Long launches take one row per frame (few places
+    // in flight = locality); short launches cut every frame into 128 segments (fine interleave of object and background tiles
+    // = balance when each wavefront only sees a few chunks).  Measured: tools/tune20.sh .. tune22.sh.
+    {
+        const uint32_t work8_r = nf * 8u / (count ? count : 1u);
+        A.perm_rows = tune("PT_TUNE_ROWS", work8_r >= 64u ? nf : (work8_r >= 8u ? 128u * nf : 64u * nf));
+    }
+    if (A.perm_rows < 1u) A.perm_rows = 1u;
+    if (A.perm_rows > 4096u) A.perm_rows = 4096u;
+    A.perm_rows_magic = A.perm_rows > 1u ? uint32_t(0x100000000ull / A.perm_rows) : 0xFFFFFFFFu;   // rows == 1: mulhi gives lb - 1 (lb > 0), corrected in the kernel
+    A.perm_cols = (A.num_batches + A.perm_rows - 1u) / A.perm_rows;
+    if (uint64_t(A.perm_cols) * A.perm_rows * 64ull > 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: batch too large (more than 2^32 items per launch)");
+    A.total_items = A.perm_cols * A.perm_rows * 64u;
     A.chunk_items = tune("PT_TUNE_CHUNK", 512u);
     {   // XCD-aware queue for long launches: 8 ranges of the logical item order, one cursor per XCD (chunk aligned; 0 = one queue).
         // Measured (tools/tune17.sh, tools/tune18.sh): 32-frame launches +2..3.5 %, HBM fetch traffic halved (L2 hit rate 85 -> 91 %);

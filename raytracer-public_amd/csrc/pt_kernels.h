@@ -80,7 +80,8 @@ struct RenderArgs {
     unsigned long long* wave_times;   // STATS diagnostics: 8 words per wave (begin, queue-empty, end ticks @100 MHz, loop counts)
     uint32_t  total_items, chunk_items;   // logical items (64*64*perm_cols) and items per queue claim
     uint32_t  xcd_span;                   // 0: one queue; else items per XCD range (8 cursors at queue[8..15])
-    uint32_t  num_batches, perm_cols;     // real (tile,sample) batches; columns of the 64-row batch transpose
+    uint32_t  num_batches, perm_cols;     // real (tile,sample) batches; columns of the batch transpose
+    uint32_t  perm_rows, perm_rows_magic; // its rows and floor(2^32 / rows) for the division
     // path pool: 64 B records (o, d, T, rad, key, item, bounce) donated by sparse wavefronts once the queue is dry;
     // they are the input of the continuation pass (off by default: PT_FLUSH_THRESHOLD 0)
     float4*   pool; uint32_t* pool_flags; uint32_t* pool_ctrl;      // ctrl: [0] reserved tail, [1] claimed head

@@ -238,12 +238,13 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                             if (STATS) ++c_closest;
                             phase = begin_ray() ? kPhaseTrav : kPhaseDone;
                         } else {
-                        // logical item -> batch permutation: 64 consecutive logical items are one
-                        // (tile, sample) batch; consecutive logical batches are perm_cols batches apart in
-                        // image order, so every claimed chunk holds the frame's average mix of hits and misses
+                        // logical item -> batch permutation: 64 consecutive logical items are one (tile, sample) batch; consecutive
+                        // logical batches are perm_cols batches apart in (frame, image) order -- a perm_rows-row transposition
                         const uint32_t logical = chunk_next + rank;
                         const uint32_t lb = logical >> 6;
-                        const uint32_t q = (lb & 63u) * A.perm_cols + (lb >> 6);
+                        uint32_t pcol = __umulhi(lb, A.perm_rows_magic), prow = lb - pcol * A.perm_rows;       // lb / rows, lb % rows (estimate, then one correction)
+                        if (prow >= A.perm_rows) { prow -= A.perm_rows; ++pcol; }
+                        const uint32_t q = prow * A.perm_cols + pcol;
                         const bool in_range = q < A.num_batches;
                         const uint32_t item = q * 64u + (logical & 63u);
                         const uint32_t p = item & 63u;
