@@ -137,6 +137,11 @@ def main():
         gathered = [torch.zeros(world, batch, stride, dtype=torch.float32, device="cuda") for _ in range(2)] if rank == 0 else [None, None]
         host_stage = backend != "nccl"   # rehearsal path (gloo): stage through host memory
         torch.cuda.synchronize()         # the zero fills ran on torch's default stream; everything below uses the context's
+    else:
+        # whole frames: every frame of a launch is delivered into its own device buffer (two launches' worth, used alternately),
+        # so no frame's result is overwritten by a later frame of the same launch
+        frames_out = torch.zeros(2 * batch, height * width * 4, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
 
     # exact traversal counters of this rank's share of every timed frame (deterministic per frame index): one instrumented
     # launch per frame, before the timed region
@@ -187,6 +192,7 @@ def main():
 
     def step(i, p):                  # called with `stream` current
         if not sharded:
+            ctx.set_output_buffer(frames_out[i % (2 * batch)].data_ptr(), height * width * 4)
             ctx.render(p)
             return
         b, j = divmod(i, batch)

@@ -194,6 +194,11 @@ int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats);
  * device_ptr = NULL restores the internal buffer.  `floats` is the buffer's capacity.  The buffer that is
  * current when a frame is submitted is that frame's target; it must outlive the frame's launch (pt_flush). */
 int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
+/* The same for whole frames (tile_count <= 1): render into a caller-owned row-major f32 RGBA device buffer of at least
+ * width*height*4 floats instead of the context's own frame buffer, e.g. one buffer per frame of a batched launch so that
+ * every frame stays available (frames of one launch that share a target leave only the last one's result, exactly as if they
+ * had been rendered one after the other).  The read-backs read the target of the last frame.  NULL restores the internal buffer. */
+int pt_set_output_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
 /* Rank 0: scatter `tile_count` gathered compact buffers (device memory, concatenated in rank
  * order, each padded to `stride_floats`) into the context's full-frame radiance buffer. */
 int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride_floats,

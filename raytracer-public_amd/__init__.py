@@ -60,7 +60,7 @@ EXPORTS = [
     "pt_compute_bvh2_sizing", "pt_compute_bvh4_sizing", "pt_morton_sort", "pt_collapse_lbvh2_to_bvh4",
     "pt_bvh2_to_bvh4_wide", "pt_file_write_u32", "pt_file_read_u32", "pt_scene_procedural",
     "pt_set_triangles", "pt_build_bvh", "pt_build_lbvh2", "pt_read_bvh2", "pt_set_bvh4", "pt_set_bvh2",
-    "pt_read_bvh4", "pt_set_spheres", "pt_scene_info", "pt_render", "pt_last_render_ms", "pt_set_batch", "pt_flush", "pt_timing_begin", "pt_timing_collect", "pt_set_compact_buffer", "pt_get_stats", "pt_read_radiance",
+    "pt_read_bvh4", "pt_set_spheres", "pt_scene_info", "pt_render", "pt_last_render_ms", "pt_set_batch", "pt_flush", "pt_timing_begin", "pt_timing_collect", "pt_set_compact_buffer", "pt_set_output_buffer", "pt_get_stats", "pt_read_radiance",
     "pt_read_rgba8", "pt_read_tonemapped", "pt_tile_layout", "pt_compact_radiance", "pt_deinterleave",
 ]
 
@@ -277,6 +277,9 @@ class Context:
 
     def set_compact_buffer(self, device_ptr, floats):
         self._ck(lib.pt_set_compact_buffer(self.h, C.c_void_p(device_ptr), C.c_uint64(floats)))
+
+    def set_output_buffer(self, device_ptr, floats):
+        self._ck(lib.pt_set_output_buffer(self.h, C.c_void_p(device_ptr), C.c_uint64(floats)))
 
     def stats(self):
         st = PtStats()

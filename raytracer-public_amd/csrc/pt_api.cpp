@@ -80,6 +80,8 @@ struct PtContext {
     uint32_t accum_w = 0, accum_h = 0, accum_count = 0, accum_rank = 0;
     uint64_t compact_floats = 0;
     float4* ext_compact = nullptr; uint64_t ext_compact_floats = 0;
+    float4* ext_out = nullptr; uint64_t ext_out_floats = 0;      // caller-owned whole-frame target (pt_set_output_buffer)
+    const float4* last_full = nullptr;                          // where the last whole-frame result lives (d_out or a caller's buffer)
     bool last_stats = false;
     std::vector<hipEvent_t> ring;    // start/stop pairs recorded by pt_render while timing is on
     uint32_t ring_used = 0;
@@ -637,8 +639,14 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         }
     } else {
         A.tiles = nullptr; A.num_tiles = A.tiles_x * tiles_y;
-        PT_HIP(ctx, ctx->d_out.ensure(npx));
-        A.out = ctx->d_out.ptr;
+        if (ctx->ext_out) {
+            if (ctx->ext_out_floats < uint64_t(npx) * 4ull) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: caller-owned output buffer too small");
+            A.out = ctx->ext_out;
+        } else {
+            PT_HIP(ctx, ctx->d_out.ensure(npx));
+            A.out = ctx->d_out.ptr;
+        }
+        ctx->last_full = A.out;
         ctx->out_w = p->width; ctx->out_h = p->height;
     }
     if (p->mode == PT_MODE_PATH && p->accumulate) {
@@ -774,7 +782,7 @@ int pt_read_radiance(PtContext* ctx, float* dst, uint64_t dst_floats) {
     const uint64_t need = uint64_t(ctx->out_w) * ctx->out_h * 4;
     if (need == 0) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_radiance: no full-frame result (render with tile_count <= 1 or call pt_deinterleave)");
     if (dst_floats < need) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_radiance: destination too small");
-    PT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_out.ptr, need * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipMemcpyAsync(dst, ctx->last_full, need * 4, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
@@ -786,7 +794,7 @@ int pt_read_rgba8(PtContext* ctx, uint8_t* dst, uint64_t dst_bytes) {
     if (npx == 0) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_rgba8: no full-frame result");
     if (!dst || dst_bytes < npx * 4) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_rgba8: destination too small");
     PT_HIP(ctx, ctx->d_u32tmp.ensure(npx));
-    PT_HIP(ctx, ptk::launch_rgba8(ctx->d_out.ptr, ctx->d_u32tmp.ptr, uint32_t(npx), ctx->stream));
+    PT_HIP(ctx, ptk::launch_rgba8(ctx->last_full, ctx->d_u32tmp.ptr, uint32_t(npx), ctx->stream));
     PT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_u32tmp.ptr, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
@@ -799,7 +807,7 @@ int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t ds
     if (npx == 0) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_tonemapped: no full-frame result");
     if (!dst || dst_bytes < npx * 4) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_tonemapped: destination too small");
     PT_HIP(ctx, ctx->d_u32tmp.ensure(npx));
-    PT_HIP(ctx, ptk::launch_tonemap(ctx->d_out.ptr, ctx->d_u32tmp.ptr, ctx->out_w, ctx->out_h, from_rgba8, ctx->stream));
+    PT_HIP(ctx, ptk::launch_tonemap(ctx->last_full, ctx->d_u32tmp.ptr, ctx->out_w, ctx->out_h, from_rgba8, ctx->stream));
     PT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_u32tmp.ptr, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
@@ -809,6 +817,13 @@ int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats) {
     if (int rc = bind(ctx)) return rc;
     ctx->ext_compact = (float4*)device_ptr;
     ctx->ext_compact_floats = device_ptr ? floats : 0;
+    return PT_OK;
+}
+
+int pt_set_output_buffer(PtContext* ctx, void* device_ptr, uint64_t floats) {
+    if (int rc = bind(ctx)) return rc;
+    ctx->ext_out = (float4*)device_ptr;
+    ctx->ext_out_floats = device_ptr ? floats : 0;
     return PT_OK;
 }
 
@@ -832,7 +847,7 @@ int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride
     const size_t npx = size_t(width) * height;
     PT_HIP(ctx, ctx->d_out.ensure(npx));
     PT_HIP(ctx, ptk::launch_deinterleave((const float4*)gathered_device, stride_floats / 4, ctx->d_out.ptr, width, height, tile_count, ctx->stream));
-    ctx->out_w = width; ctx->out_h = height;
+    ctx->out_w = width; ctx->out_h = height; ctx->last_full = ctx->d_out.ptr;
     return PT_OK;
 }
 

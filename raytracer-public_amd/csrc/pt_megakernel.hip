@@ -411,10 +411,15 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
     }
 }
 
-// Sum the samples of each owned pixel in sample order; carry the running sum when accumulating.
+// Sum the samples of each owned pixel in sample order; carry the running sum when accumulating.  blockIdx.y = frame of
+// the batch when the frames are independent (ACCUM false); an accumulating sequence walks its frames in submission order
+// (the running sum is order dependent).  Samples are read four at a time before their slots are re-primed, so a wavefront
+// keeps several loads in flight: the pass runs next to a persistent launch that leaves it about one wave slot per SIMD.
+template <bool ACCUM>
 __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t slot = idx >> 6, p = idx & 63u;
+    if (idx == 0u && blockIdx.y == 0u) { for (int k = 0; k < 16; ++k) A.queue[k] = 0u; }   // the slot's control block rewound for its next launch
     if (slot >= A.num_tiles) return;
     const uint32_t tile = A.tiles ? A.tiles[slot] : slot;
     const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
@@ -422,20 +427,36 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
     if (px >= A.width || py >= A.height) return;
     const size_t out_index = A.compact ? (size_t)idx : ((size_t)py * A.width + px);
     const float bg = 0.0f + 1.0f * kBgPrimary;
+    const float4 prime = make_float4(bg, bg, bg, 1.0f);
     const FrameParams* const frames = (const FrameParams*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(RenderArgs, frames));
     float4* const* const outs = (float4* const*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(RenderArgs, outs));
-    // frames of a batched launch are resolved in submission order (the running sum of an accumulating sequence is order-dependent)
-    for (uint32_t fid = 0; fid < A.num_frames; ++fid) {
+    const uint32_t f_begin = ACCUM ? 0u : blockIdx.y, f_end = ACCUM ? A.num_frames : blockIdx.y + 1u;
+    for (uint32_t fid = f_begin; fid < f_end; ++fid) {
         F3 sum = f3(0.0f, 0.0f, 0.0f);
-        for (uint32_t s = 0; s < A.spp; ++s) {
-            float4* sp = A.samples + (((size_t)fid * A.batches_per_frame + (size_t)slot * A.spp + s) * 64u + p);
-            const float4 v = *sp;
-            sum = sum + f3(v.x, v.y, v.z);
-            *sp = make_float4(bg, bg, bg, 1.0f);     // leave the slot primed for its next frame (no separate prefill pass)
+        float4* const sp = A.samples + (((size_t)fid * A.batches_per_frame + (size_t)slot * A.spp) * 64u + p);   // sample s at sp[s * 64]
+        if (!ACCUM) {
+            // independent frames resolve in parallel; where several share one output target the last submitted one is the
+            // result (what resolving them in order would leave), the others only hand their sample slots back
+            bool superseded = false;
+            for (uint32_t g = fid + 1u; g < A.num_frames; ++g) superseded |= (outs[g] == outs[fid]);
+            if (superseded) {
+                for (uint32_t s = 0; s < A.spp; ++s) sp[(size_t)s * 64u] = prime;
+                continue;
+            }
+        }
+        for (uint32_t s0 = 0; s0 < A.spp; s0 += 4u) {
+            const uint32_t n = min(4u, A.spp - s0);
+            float4 v[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) v[j] = (j < n) ? sp[(size_t)(s0 + j) * 64u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) if (j < n) sum = sum + f3(v[j].x, v[j].y, v[j].z);
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) if (j < n) sp[(size_t)(s0 + j) * 64u] = prime;     // leave the slot primed for its next frame (no separate prefill pass)
         }
         float count = (float)A.spp;
-        const uint32_t am = frames[fid].accum_mode;
-        if (am != 0u) {
+        if (ACCUM) {
+            const uint32_t am = frames[fid].accum_mode;
             const float4 acc = (am == 2u) ? A.accum[out_index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             sum = f3(acc.x + sum.x, acc.y + sum.y, acc.z + sum.z);
             count = acc.w + count;
@@ -444,7 +465,6 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
         const float inv = 1.0f / count;
         outs[fid][out_index] = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, 1.0f);
     }
-    if (idx == 0u) { for (int k = 0; k < 16; ++k) A.queue[k] = 0u; }   // and its control block rewound
 }
 
 // every sample starts as the camera-ray miss value 0 + 1 * 0.01 (renderer.wgsl:410)
@@ -507,7 +527,8 @@ hipError_t launch_trace(const RenderArgs& A0, bool stats, uint32_t grid_blocks, 
 hipError_t launch_resolve(const RenderArgs& A, hipStream_t stream) {
     if (A.total_items == 0u) return hipSuccess;
     const uint32_t n = A.num_tiles * 64u;
-    hipLaunchKernelGGL(resolve_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, A);
+    if (A.accum) hipLaunchKernelGGL(resolve_kernel<true>, dim3((n + 255u) / 256u, 1), dim3(256), 0, stream, A);
+    else         hipLaunchKernelGGL(resolve_kernel<false>, dim3((n + 255u) / 256u, A.num_frames), dim3(256), 0, stream, A);
     return hipGetLastError();
 }
 

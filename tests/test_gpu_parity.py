@@ -306,6 +306,51 @@ def test_batched_launch_equals_frame_by_frame(rt, gpu_ctx):
     assert same_bits(got, ref)
 
 
+def test_whole_frame_output_buffers_in_a_batch(rt, gpu_ctx):
+    """pt_set_output_buffer: each frame of a batched launch lands in the caller's buffer that was current at submission;
+    frames that share a target leave the last submitted frame's result (what one launch per frame would leave)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    tris = rt.procedural_scene(0, 15000)
+    gpu_ctx.set_triangles(tris); gpu_ctx.build_bvh()
+    w, h, nf = 150, 90, 5
+    def params(f):
+        return gpu_ctx.make_params(w, h, (0.1 * f, 0, 2.5), (0, 0, 0, 1), mode=rt.PT_MODE_PATH, spp=5, max_bounces=3, seed=8, frame=f)
+    want = []
+    for f in range(nf):
+        gpu_ctx.render(params(f)); want.append(gpu_ctx.read_radiance().copy())
+    floats = w * h * 4
+    bufs = []
+    for f in range(nf):
+        p = C.c_void_p(); assert hip.hipMalloc(C.byref(p), C.c_size_t(floats * 4)) == 0; bufs.append(p)
+    gpu_ctx.set_batch(nf)
+    for f in range(nf):
+        gpu_ctx.set_output_buffer(bufs[f].value, floats)
+        gpu_ctx.render(params(f))
+    last = gpu_ctx.read_radiance().copy()                      # launches the batch; reads the last frame's target
+    assert same_bits(last, want[nf - 1])
+    for f in range(nf):
+        host = np.zeros((h, w, 4), np.float32)
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), bufs[f], C.c_size_t(floats * 4), 2) == 0
+        assert same_bits(host, want[f]), f
+    # all frames into ONE caller-owned buffer, then into the context's own: the last frame's result stays
+    gpu_ctx.set_output_buffer(bufs[0].value, floats)
+    for f in range(nf):
+        gpu_ctx.render(params(f))
+    assert same_bits(gpu_ctx.read_radiance(), want[nf - 1])
+    gpu_ctx.set_output_buffer(0, 0)
+    for f in range(nf):
+        gpu_ctx.render(params(f))
+    assert same_bits(gpu_ctx.read_radiance(), want[nf - 1])
+    with pytest.raises(rt.PtError):
+        gpu_ctx.set_output_buffer(bufs[0].value, floats - 4)
+        gpu_ctx.render(params(0))
+    gpu_ctx.set_output_buffer(0, 0)
+    gpu_ctx.set_batch(1)
+    for b in bufs:
+        hip.hipFree(b)
+
+
 def test_largest_batch_accumulates_like_single_launches(rt, gpu_ctx):
     """32 frames (the pt_set_batch maximum) in one launch, accumulated: the running sum is the one 32 launches give."""
     tris = rt.procedural_scene(0, 12000)
