@@ -13,7 +13,7 @@ if os.environ.get("PB_TORCH") == "2":
     st = torch.cuda.Stream(); ctx.set_stream(st.cuda_stream)
 ctx.set_triangles(tris); ctx.build_bvh()
 tc = int(os.environ.get('PB_TILES', '1'))
-p = ctx.make_params(1920, 1080, cam, quat, mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, tile_rank=0, tile_count=tc)
+p = ctx.make_params(1920, 1080, cam, quat, mode=rt.PT_MODE_PATH, spp=int(os.environ.get('PB_SPP', '4')), max_bounces=int(os.environ.get('PB_BOUNCES', '8')), tile_rank=0, tile_count=tc)
 B = int(os.environ.get('PB_BATCH', '1')); ctx.set_batch(B)
 for _ in range(8 * B): ctx.render(p)
 ctx.synchronize()
@@ -29,4 +29,4 @@ dt = time.perf_counter() - t0
 if os.environ.get("PB_RING"):
     ms = ctx.timing_collect(n); print("ring: kernel avg %.3f ms" % ms.mean())
 print("tiles 1/%d batch=%d " % (tc, B), end="")
-print("slots=%s: %.3f ms/frame, %.0f Msamples/s" % (os.environ.get("PT_TUNE_SLOTS", "default"), dt / n * 1e3, 1920 * 1080 * 4 * n / dt / 1e6))
+print("slots=%s: %.3f ms/frame, %.0f Msamples/s" % (os.environ.get("PT_TUNE_SLOTS", "default"), dt / n * 1e3, 1920 * 1080 * p.spp * n / dt / 1e6))
