@@ -41,15 +41,16 @@ __global__ void build_init_kernel(unsigned long long* bounds, uint32_t* counters
     if (i < n_counters) counters[i] = 0u;
 }
 
-// lo = min over centroids (c < lo ? c : lo), hi = max: NaN never wins a comparison, values beyond +-1e30 never win either
+// lo = min over centroids (c < lo ? c : lo), hi = max: NaN never wins a comparison, values beyond +-1e30 never win either.
+// Grid-stride over the triangles, wavefront shuffle + LDS reduction: six atomics per block.
 __global__ __launch_bounds__(256) void centroid_bounds_kernel(const float* __restrict__ tris, uint32_t n, unsigned long long* bounds) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned long long part[4][6];
     unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};
-    if (t < n) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         const float* p = tris + (size_t)t * 9;
         for (int k = 0; k < 3; ++k) {
             const double c = centroid_axis(p, k);
-            if (c == c) { lo[k] = hi[k] = dkey(c); }
+            if (c == c) { const unsigned long long key = dkey(c); lo[k] = key < lo[k] ? key : lo[k]; hi[k] = key > hi[k] ? key : hi[k]; }
         }
     }
     for (int k = 0; k < 3; ++k) {
@@ -59,8 +60,14 @@ __global__ __launch_bounds__(256) void centroid_bounds_kernel(const float* __res
             hi[k] = b > hi[k] ? b : hi[k];
         }
     }
-    if ((threadIdx.x & 63u) == 0u) {
-        for (int k = 0; k < 3; ++k) { atomicMin(&bounds[k], lo[k]); atomicMax(&bounds[3 + k], hi[k]); }
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u) { for (int k = 0; k < 3; ++k) { part[wave][k] = lo[k]; part[wave][3 + k] = hi[k]; } }
+    __syncthreads();
+    if (threadIdx.x < 6u) {
+        const uint32_t k = threadIdx.x;
+        unsigned long long v = part[0][k];
+        for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) { const unsigned long long o = part[w][k]; v = (k < 3u) ? (o < v ? o : v) : (o > v ? o : v); }
+        if (k < 3u) atomicMin(&bounds[k], v); else atomicMax(&bounds[k], v);
     }
 }
 
@@ -305,7 +312,7 @@ hipError_t launch_tri_records(const float* tris9, uint32_t num_tris, float4* rec
 hipError_t launch_morton_sort(const BuildBuffers& B, const float* tris9, uint32_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(build_init_kernel, dim3(1), dim3(256), 0, stream, B.bounds, B.counters, (uint32_t)kBuildCounters);
-    hipLaunchKernelGGL(centroid_bounds_kernel, dim3(blocks(n)), dim3(256), 0, stream, tris9, n, B.bounds);
+    hipLaunchKernelGGL(centroid_bounds_kernel, dim3(blocks(n) < 1024u ? blocks(n) : 1024u), dim3(256), 0, stream, tris9, n, B.bounds);
     hipLaunchKernelGGL(morton_kernel, dim3(blocks(n)), dim3(256), 0, stream, tris9, n, B.bounds, B.code_tmp, B.index_tmp);
     hipError_t e = hipGetLastError(); if (e != hipSuccess) return e;
     size_t bytes = B.temp_bytes;
