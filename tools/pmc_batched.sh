@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PB_BATCH=32 PB_VARY=1      # 32 different frames (frame indices) per launch, as bench.py submits them
 i=0
-for CNT in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+for CNT in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $CNT --output-format csv -d $OUT/pass$i -- python $GRAFT_REPO_ROOT/tools/pipeline_bench.py 32 > $OUT/pass$i.log 2>&1 || echo "pass $i failed" >> $OUT/errors.txt
 done
