@@ -150,7 +150,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     // multiple or a divisor of the frame count keep the frames of a launch aligned: all rows are at the same image position at
     // the same time, so the frames share the BVH nodes they pull through L2.  Long launches take one row per frame (few places
     // in flight = locality); short launches cut every frame into 128 segments (fine interleave of object and background tiles
-    // = balance when each wavefront only sees a few chunks).  Measured: tools/tune20.sh .. tune22.sh.
+    // = balance when each wavefront only sees a few chunks).  Measured: tools/sweeps/tune20.sh .. tune22.sh.
     {
         const uint32_t work8_r = nf * 8u / (count ? count : 1u);
         A.perm_rows = tune("PT_TUNE_ROWS", work8_r >= 64u ? nf : (work8_r >= 8u ? 128u * nf : 64u * nf));
@@ -163,7 +163,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     A.total_items = A.perm_cols * A.perm_rows * 64u;
     A.chunk_items = tune("PT_TUNE_CHUNK", 512u);
     {   // XCD-aware queue for long launches: 8 ranges of the logical item order, one cursor per XCD (chunk aligned; 0 = one queue).
-        // Measured (tools/tune17.sh, tools/tune18.sh): 32-frame launches +2..3.5 %, HBM fetch traffic halved (L2 hit rate 85 -> 91 %);
+        // Measured (tools/sweeps/tune17.sh, tools/sweeps/tune18.sh): 32-frame launches +2..3.5 %, HBM fetch traffic halved (L2 hit rate 85 -> 91 %);
         // no gain at 8 frames of work, a loss for a single frame (the ranges are not equally heavy).
         const uint32_t per = (A.total_items + 7u) / 8u;
         const uint32_t work8_q = nf * 8u / (count ? count : 1u);
@@ -175,7 +175,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
     // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
     // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small
-    // sharded launches need several in flight to fill the chip.  Measured: tools/tune13.sh, tools/tune14.sh.
+    // sharded launches need several in flight to fill the chip.  Measured: tools/sweeps/tune13.sh, tools/sweeps/tune14.sh.
     const uint32_t work8 = nf * 8u / (count ? count : 1u);      // eighths of a whole frame
     int want_slots = int(tune("PT_TUNE_SLOTS", work8 >= 64u ? 2u : (work8 >= 16u ? PT_FRAME_SLOTS : (work8 >= 8u ? (sharded ? 4u : PT_FRAME_SLOTS) : (sharded ? 8u : PT_FRAME_SLOTS)))));
     if (want_slots < 1) want_slots = 1;

@@ -21,7 +21,7 @@
 #define PT_MEGA_BLOCK 64           // threads per workgroup of the persistent kernel: single-wave groups free their CU slot as soon as the wave drains
 #endif
 #ifndef PT_SHADE_THRESHOLD
-#define PT_SHADE_THRESHOLD 16       // lanes waiting for a shade pass before one runs (or nothing traverses); 16 measured best in long launches, 8..16 equal for single frames (tools/tune26.sh)
+#define PT_SHADE_THRESHOLD 16       // lanes waiting for a shade pass before one runs (or nothing traverses); 16 measured best in long launches, 8..16 equal for single frames (tools/sweeps/tune26.sh)
 #endif
 #ifndef PT_FLUSH_THRESHOLD
 #define PT_FLUSH_THRESHOLD 0       // >0: once the queue is dry, a wavefront with fewer live lanes donates its paths to the next pass (measured: no gain at <= 4 frame slots, so off)
