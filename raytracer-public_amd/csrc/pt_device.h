@@ -29,6 +29,10 @@ __device__ __forceinline__ float wmax(float a, float b) { return __builtin_fmaxf
 __device__ __forceinline__ float half_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
 __device__ __forceinline__ float half_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
 
+// float(low / high half of w) - o in one instruction
+__device__ __forceinline__ float half_lo_minus(uint32_t w, float o) { float r; asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(o)); return r; }
+__device__ __forceinline__ float half_hi_minus(uint32_t w, float o) { float r; asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(o)); return r; }
+
 constexpr float kInfT = 1e30f;          // renderer.wgsl:64
 constexpr float kTriEps = 1e-7f;        // renderer.wgsl:178
 constexpr uint32_t kLeaf = 0x80000000u;
@@ -73,9 +77,11 @@ __device__ __forceinline__ Ray primary_ray_fp(const RenderArgs& A, const FramePa
 
 // slab test of one packed f16 box (renderer.wgsl:147-159); returns hit, writes tmin
 __device__ __forceinline__ bool slab(const Ray& r, uint32_t w0, uint32_t w1, uint32_t w2, float best, float& tmin_out) {
-    const F3 mn = f3(half_lo(w0), half_hi(w0), half_lo(w1));
-    const F3 mx = f3(half_hi(w1), half_lo(w2), half_hi(w2));
-    const F3 t1 = (mn - r.o) * r.inv, t2 = (mx - r.o) * r.inv;
+    // (bound - origin) straight from the packed halves: v_fma_mix_f32 widens an f16 source on the fly, and fma(h, 1.0, -o) is the
+    // f32 subtraction (one rounding of the exact difference) -- bit-identical to v_cvt_f32_f16 + v_sub_f32 for every half value
+    // (tools/probes/fma_mix.hip), one instruction instead of two, 24 fewer per node
+    const F3 t1 = f3(half_lo_minus(w0, r.o.x), half_hi_minus(w0, r.o.y), half_lo_minus(w1, r.o.z)) * r.inv;
+    const F3 t2 = f3(half_hi_minus(w1, r.o.x), half_lo_minus(w2, r.o.y), half_hi_minus(w2, r.o.z)) * r.inv;
     const float tmin = wmax(wmax(wmin(t1.x, t2.x), wmin(t1.y, t2.y)), wmin(t1.z, t2.z));
     const float tmax = wmin(wmin(wmax(t1.x, t2.x), wmax(t1.y, t2.y)), wmax(t1.z, t2.z));
     tmin_out = tmin;
