@@ -144,6 +144,10 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     }
     const uint32_t grid_lanes = grid * ptk::megakernel_block();
     A.num_frames = nf;
+    if (uint64_t(A.num_tiles) * A.spp * nf * 64ull > 0xFFFFFFFFull) {     // item and sample indices are 32-bit
+        ctx->pending = 0;
+        return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: more than 2^32 pixel-samples in one launch (lower spp, the resolution or the batch)");
+    }
     A.batches_per_frame = A.num_tiles * A.spp;
     A.num_batches = A.batches_per_frame * nf;
     // Rows of the batch transposition (the order in which the queue walks the (frame, tile, sample) batches).  Rows that are a
@@ -670,6 +674,8 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     const int kmode = p->mode == PT_MODE_REFERENCE_PACKET ? PT_KMODE_PACKET : (p->mode == PT_MODE_REFERENCE ? PT_KMODE_REFERENCE : PT_KMODE_PATH);
     if (kmode == PT_KMODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute) {
         // ---- persistent megakernel: frames are queued and launched in batches of ctx->batch_size
+        if (uint64_t(A.num_tiles) * A.spp * 64ull * ctx->batch_size > 0xFFFFFFFFull)      // item and sample indices are 32-bit
+            return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: more than 2^32 pixel-samples per launch (lower spp, the resolution or pt_set_batch)");
         ptk::FrameParams fp; std::memset(&fp, 0, sizeof(fp));
         std::memcpy(fp.cam, p->cam_pos, 12); std::memcpy(fp.quat, p->cam_quat, 16);
         fp.focal = p->focal; fp.aspect = p->aspect; fp.frame = p->frame; fp.seed = p->seed;

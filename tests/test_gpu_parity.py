@@ -371,6 +371,15 @@ def test_largest_batch_accumulates_like_single_launches(rt, gpu_ctx):
         gpu_ctx.set_batch(33)
 
 
+def test_too_many_samples_per_launch_is_rejected(rt, gpu_ctx):
+    gpu_ctx.set_triangles(rt.procedural_scene(0, 12000)); gpu_ctx.build_bvh()
+    with pytest.raises(rt.PtError) as e:
+        gpu_ctx.render(gpu_ctx.make_params(4096, 4096, mode=rt.PT_MODE_PATH, spp=512, max_bounces=1))     # 2^33 samples
+    assert e.value.code == 1 and "2^32" in str(e.value)
+    gpu_ctx.render(gpu_ctx.make_params(64, 64, mode=rt.PT_MODE_PATH, spp=2, max_bounces=1))                # the context is still usable
+    assert np.isfinite(gpu_ctx.read_radiance()).all()
+
+
 def test_error_paths(rt, gpu_ctx):
     fresh = rt.Context(0)
     with pytest.raises(rt.PtError) as e:
