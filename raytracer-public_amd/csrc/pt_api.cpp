@@ -45,6 +45,7 @@ struct PtContext {
     // scene (host mirrors kept for rebuilds / readback of small metadata only)
     uint32_t num_tris = 0, num_nodes2 = 0, num_nodes4 = 0;
     bool have_tris = false, have_bvh = false, have_bvh2 = false;
+    bool bvh2_refit_pending = false;  // pt_build_bvh leaves the internal BVH2 bounds to the first pt_read_bvh2 (nothing on the render path reads them)
     pt::WideBvh wide_meta;           // root info; nodes vector emptied after upload
 
     DevBuf<float> d_tris9;           // reference layout
@@ -411,7 +412,7 @@ int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris) {
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->num_tris = num_tris;
     ctx->have_tris = true;
-    ctx->have_bvh = false; ctx->have_bvh2 = false;
+    ctx->have_bvh = false; ctx->have_bvh2 = false; ctx->bvh2_refit_pending = false;
     ctx->accum_count = 0;
     return PT_OK;
 }
@@ -436,7 +437,8 @@ int pt_build_lbvh2(PtContext* ctx, const uint32_t* morton_sorted, const uint32_t
     PT_HIP(ctx, ctx->d_parent.ensure(nn2)); PT_HIP(ctx, ctx->d_flags.ensure(n > 1 ? n - 1 : 1));
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_morton.ptr, morton_sorted, size_t(n) * 4, hipMemcpyHostToDevice, ctx->stream));
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_triidx.ptr, tri_index_sorted, size_t(n) * 4, hipMemcpyHostToDevice, ctx->stream));
-    PT_HIP(ctx, ptk::launch_lbvh2(ctx->d_bvh2.ptr, ctx->d_tris9.ptr, ctx->d_morton.ptr, ctx->d_triidx.ptr, ctx->d_parent.ptr, ctx->d_flags.ptr, n, ctx->stream));
+    PT_HIP(ctx, ptk::launch_lbvh2(ctx->d_bvh2.ptr, ctx->d_tris9.ptr, ctx->d_morton.ptr, ctx->d_triidx.ptr, ctx->d_parent.ptr, ctx->d_flags.ptr, n, true, ctx->stream));
+    ctx->bvh2_refit_pending = false;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // device.queue.onSubmittedWorkDone(), PathTracer.js:727
     ctx->have_bvh2 = true;
     return PT_OK;
@@ -448,6 +450,10 @@ int pt_read_bvh2(PtContext* ctx, uint32_t* dst, uint64_t bytes) {
     if (!dst) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_bvh2: null destination");
     uint64_t have = 0; pt_compute_bvh2_sizing(ctx->num_tris, nullptr, &have);
     const uint64_t n = bytes < have ? bytes : have;
+    if (ctx->bvh2_refit_pending) {                  // BVHBuilder.wgsl:242-275, deferred by pt_build_bvh
+        PT_HIP(ctx, ptk::launch_lbvh2_refit(ctx->d_bvh2.ptr, ctx->d_parent.ptr, ctx->d_flags.ptr, ctx->num_tris, ctx->stream));
+        ctx->bvh2_refit_pending = false;
+    }
     PT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_bvh2.ptr, n, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
@@ -470,7 +476,7 @@ int pt_set_bvh2(PtContext* ctx, const uint32_t* bvh2, uint64_t words) {
     PT_HIP(ctx, ctx->d_bvh2.ensure(bytes / 4));
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh2.ptr, bvh2, bytes, hipMemcpyHostToDevice, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->num_nodes2 = nn2; ctx->have_bvh2 = true;
+    ctx->num_nodes2 = nn2; ctx->have_bvh2 = true; ctx->bvh2_refit_pending = false;
     std::vector<uint32_t> b4; std::string err;
     if (!pt::collapse_to_bvh4(bvh2, ctx->num_tris, b4, err)) return fail(ctx, PT_ERR_BAD_BVH, err);
     ctx->accum_count = 0;
@@ -510,7 +516,8 @@ int pt_build_bvh(PtContext* ctx) {
     ctx->have_bvh = false; ctx->have_bvh2 = false;
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh2.ptr, &nn2, 4, hipMemcpyHostToDevice, ctx->stream));   // BVH2[0] = numNodes2, PathTracer.js:699
     PT_HIP(ctx, ptk::launch_morton_sort(B, ctx->d_tris9.ptr, n, ctx->stream));
-    PT_HIP(ctx, ptk::launch_lbvh2(ctx->d_bvh2.ptr, ctx->d_tris9.ptr, ctx->d_morton.ptr, ctx->d_triidx.ptr, ctx->d_parent.ptr, ctx->d_flags.ptr, n, ctx->stream));
+    PT_HIP(ctx, ptk::launch_lbvh2(ctx->d_bvh2.ptr, ctx->d_tris9.ptr, ctx->d_morton.ptr, ctx->d_triidx.ptr, ctx->d_parent.ptr, ctx->d_flags.ptr, n, false, ctx->stream));
+    ctx->bvh2_refit_pending = true;                 // internal BVH2 bounds: on demand (pt_read_bvh2)
     ctx->num_nodes2 = nn2;
     uint32_t m = 0;
     {

@@ -101,8 +101,10 @@ hipError_t launch_prime(uint32_t* queue, float4* samples, uint32_t n_samples, hi
 hipError_t launch_resolve(const RenderArgs& args, hipStream_t stream);
 uint32_t megakernel_grid(int num_cus);
 uint32_t megakernel_block();
+// refit = false leaves the internal BVH2 nodes without bounds (the BVH4 collapse does not read them); launch_lbvh2_refit adds them
 hipError_t launch_lbvh2(uint32_t* bvh2, const float* tris9, const uint32_t* morton, const uint32_t* tri_index,
-                        uint32_t* parent, uint32_t* flags, uint32_t num_tris, hipStream_t stream);
+                        uint32_t* parent, uint32_t* flags, uint32_t num_tris, bool refit, hipStream_t stream);
+hipError_t launch_lbvh2_refit(uint32_t* bvh2, const uint32_t* parent, uint32_t* flags, uint32_t num_tris, hipStream_t stream);
 // ---- device-side scene build (pt_build.hip) -------------------------------------------------
 constexpr int kBuildCounters = 256;      // one append counter per BVH4 level (an LBVH2 over 30-bit codes + index bits is < 64 deep)
 struct BuildBuffers {

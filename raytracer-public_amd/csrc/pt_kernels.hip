@@ -419,21 +419,27 @@ __global__ __launch_bounds__(256) void lbvh2_internal_kernel(uint32_t* __restric
     if (iu == 0u) parent[0] = kInvalidRef;
 }
 
+// REFIT = false: only the leaf records (all the BVH4 collapse needs: it re-unions bounds from the leaves up);
+// REFIT = true : leaf records and the bottom-up walk that gives the internal BVH2 nodes their bounds;
+// LEAVES = false with REFIT: the walk alone, over leaf records written by an earlier launch (pt_read_bvh2 after pt_build_bvh).
+template <bool LEAVES, bool REFIT>
 __global__ __launch_bounds__(256) void lbvh2_leaves_kernel(uint32_t* bvh2, const float* __restrict__ tris, const uint32_t* __restrict__ tri_index,
                                                             const uint32_t* __restrict__ parent, uint32_t* flags, uint32_t num_tris) {
     const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;   // BVHBuilder.wgsl:278-306
     if (leaf >= num_tris) return;
     const uint32_t internal = num_tris - 1u;
     const uint32_t node = internal + leaf;
-    const uint32_t ti = tri_index[leaf];
-    const float* tp = tris + (size_t)ti * 9;
-    const F3 v0 = f3(tp[0], tp[1], tp[2]), v1 = f3(tp[3], tp[4], tp[5]), v2 = f3(tp[6], tp[7], tp[8]);
-    const F3 mn = f3(wmin(v0.x, wmin(v1.x, v2.x)), wmin(v0.y, wmin(v1.y, v2.y)), wmin(v0.z, wmin(v1.z, v2.z)));
-    const F3 mx = f3(wmax(v0.x, wmax(v1.x, v2.x)), wmax(v0.y, wmax(v1.y, v2.y)), wmax(v0.z, wmax(v1.z, v2.z)));
-    store_bounds2(bvh2, node, mn, mx);
-    uint32_t* p = bvh2 + 1 + (size_t)node * 6;
-    p[3] = 0u; p[4] = 0u; p[5] = kLeaf | (ti & 0x7fffffffu);
-    if (internal == 0u) return;
+    if (LEAVES) {
+        const uint32_t ti = tri_index[leaf];
+        const float* tp = tris + (size_t)ti * 9;
+        const F3 v0 = f3(tp[0], tp[1], tp[2]), v1 = f3(tp[3], tp[4], tp[5]), v2 = f3(tp[6], tp[7], tp[8]);
+        const F3 mn = f3(wmin(v0.x, wmin(v1.x, v2.x)), wmin(v0.y, wmin(v1.y, v2.y)), wmin(v0.z, wmin(v1.z, v2.z)));
+        const F3 mx = f3(wmax(v0.x, wmax(v1.x, v2.x)), wmax(v0.y, wmax(v1.y, v2.y)), wmax(v0.z, wmax(v1.z, v2.z)));
+        store_bounds2(bvh2, node, mn, mx);
+        uint32_t* p = bvh2 + 1 + (size_t)node * 6;
+        p[3] = 0u; p[4] = 0u; p[5] = kLeaf | (ti & 0x7fffffffu);
+    }
+    if (!REFIT || internal == 0u) return;
     // bottom-up refit (BVHBuilder.wgsl:242-275).  The reference has no fence between a child's
     // bounds store and the flag increment; here the stores are agent-scope, a release fence
     // precedes the atomic and an acquire fence follows it (MI355X L2s are per XCD).
@@ -532,13 +538,21 @@ hipError_t launch_render(const RenderArgs& A, int kmode, bool stats, hipStream_t
 }
 
 hipError_t launch_lbvh2(uint32_t* bvh2, const float* tris9, const uint32_t* morton, const uint32_t* tri_index,
-                        uint32_t* parent, uint32_t* flags, uint32_t num_tris, hipStream_t stream) {
+                        uint32_t* parent, uint32_t* flags, uint32_t num_tris, bool refit, hipStream_t stream) {
     if (num_tris == 0) return hipSuccess;
     if (num_tris > 1) {
         hipLaunchKernelGGL(lbvh2_internal_kernel, dim3((num_tris - 1 + 255) / 256), dim3(256), 0, stream, bvh2, morton, parent, flags, num_tris);
         hipError_t e = hipGetLastError(); if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(lbvh2_leaves_kernel, dim3((num_tris + 255) / 256), dim3(256), 0, stream, bvh2, tris9, tri_index, parent, flags, num_tris);
+    if (refit) hipLaunchKernelGGL((lbvh2_leaves_kernel<true, true>), dim3((num_tris + 255) / 256), dim3(256), 0, stream, bvh2, tris9, tri_index, parent, flags, num_tris);
+    else       hipLaunchKernelGGL((lbvh2_leaves_kernel<true, false>), dim3((num_tris + 255) / 256), dim3(256), 0, stream, bvh2, tris9, tri_index, parent, flags, num_tris);
+    return hipGetLastError();
+}
+
+// the bottom-up walk alone (the arrival flags are still zero from lbvh2_internal_kernel)
+hipError_t launch_lbvh2_refit(uint32_t* bvh2, const uint32_t* parent, uint32_t* flags, uint32_t num_tris, hipStream_t stream) {
+    if (num_tris <= 1) return hipSuccess;
+    hipLaunchKernelGGL((lbvh2_leaves_kernel<false, true>), dim3((num_tris + 255) / 256), dim3(256), 0, stream, bvh2, nullptr, nullptr, parent, flags, num_tris);
     return hipGetLastError();
 }
 
