@@ -51,6 +51,36 @@ def cpu_baseline(tris, bvh4):
                       % (st["samples"], dt, os.cpu_count() or 0)}, st
 
 
+def cpu_baseline_threads(tris, bvh4):
+    """The same oracle over row bands on several host threads (ctypes releases the GIL; bands write disjoint rows), for
+    context: the whole frame again.  Thread count = the CPU share of a one-GPU box (16) or fewer."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc as orc_mod
+    orc = orc_mod.load()
+    threads = max(1, min(16, os.cpu_count() or 1))
+    tris = np.ascontiguousarray(tris, np.float32).reshape(-1); bvh4 = np.ascontiguousarray(bvh4, np.uint32)
+    img = np.zeros((HEIGHT, WIDTH, 4), np.float32)
+    bands = [(y, min(y + 8, HEIGHT)) for y in range(0, HEIGHT, 8)]          # 8-row bands, handed out dynamically
+
+    def work(band):
+        p = orc.make_params(WIDTH, HEIGHT, NUM_TRIS, mode=orc_mod.MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED, rect=(0, band[0], WIDTH, band[1]))
+        st = orc_mod.Stats()
+        rc = orc.lib.orc_render(C.byref(p), tris.ctypes.data_as(C.POINTER(C.c_float)), bvh4.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                img.ctypes.data_as(C.POINTER(C.c_float)), None, C.byref(st))
+        assert rc == 0
+        return st.samples
+
+    t0 = time.time()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        samples = sum(ex.map(work, bands))
+    dt = time.time() - t0
+    return {"value": round(samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": "every pixel of the same frame in 8-row bands over %d host threads (%d samples, %.1f s), oracle/pt_oracle.cpp" % (threads, samples, dt)}
+
+
 def cpu_baseline_node(tris, bvh4):
     """The same loop as a single-thread Node/JS program (oracle/js/pt_oracle.js, bit-identical to the C++
     oracle): every 2nd pixel in x and y of the same frame."""
@@ -288,6 +318,7 @@ def main():
             bvh4 = ctx.read_bvh4()
             base, ost = cpu_baseline(tris, bvh4)
             out["cpu_baseline"] = base
+            out["cpu_baseline_threads"] = cpu_baseline_threads(tris, bvh4)
             out["cpu_baseline_node"] = cpu_baseline_node(tris, bvh4)
         else:
             out["cpu_baseline"] = None
