@@ -131,8 +131,10 @@ int pt_scene_procedural(uint32_t kind, uint32_t seed, uint32_t num_tris, float* 
 /* device.queue.writeBuffer(triangles) (PathTracer.js:679); N <= 932,067 in the reference
  * (32 MiB buffer, :140-143) -- no such cap here. */
 int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris);
-/* buildBVH (PathTracer.js:671-749): Morton+sort, LBVH2 kernels (BVHBuilder.wgsl), readback,
- * greedy collapse to BVH4, upload. */
+/* buildBVH (PathTracer.js:671-749): Morton codes + sort (:411-481), LBVH2 kernels (BVHBuilder.wgsl), greedy collapse to
+ * BVH4 (:506-667) -- every step on the device, same BVH2 / BVH4 buffers bit for bit as the reference's CPU + WebGPU split
+ * (the host entry points below mirror the JS steps one by one).  The bounds of the INTERNAL BVH2 nodes, which only a BVH2
+ * read-back looks at, are filled in by the first pt_read_bvh2. */
 int pt_build_bvh(PtContext* ctx);
 /* LBVH2 kernels only, from caller-supplied sorted codes (the two dispatches at
  * PathTracer.js:709-728); result stays on the device for pt_read_bvh2. */
