@@ -47,13 +47,13 @@ def main():
             spp, bounces = int(rng.integers(1, 7)), int(rng.integers(0, 11))
             inside = kind == 1 or rng.random() < 0.2
             cams = []
-            nf = int(rng.integers(1, 13))
+            nf = int(rng.integers(1, 13)) if rng.random() < 0.8 else int(rng.integers(13, 41))       # sometimes more than one full launch
             for f in range(nf):
                 pos = rng.uniform(-0.6, 0.6, 3) if inside else rng.uniform(-1, 1, 3) * 0.5 + np.array([0, 0, 2.4])
                 cams.append((tuple(float(v) for v in pos), quat(rng.uniform(-3.2, 3.2) if inside else rng.uniform(-0.3, 0.3), rng.uniform(-0.5, 0.5))))
             accumulate = bool(rng.random() < 0.35)
             count = int(rng.choice([1, 1, 2, 3, 4, 8])) if not accumulate else 1
-            batch = int(rng.integers(1, 13))
+            batch = int(rng.integers(1, 13)) if rng.random() < 0.8 else int(rng.integers(13, 33))
             sd = int(rng.integers(0, 2 ** 31))
             cfg = dict(kind=kind, n=n, w=w, h=h, spp=spp, bounces=bounces, nf=nf, accumulate=accumulate, count=count, batch=batch, seed=sd)
             kw = dict(mode=rt.PT_MODE_PATH, spp=spp, max_bounces=bounces, seed=sd)
