@@ -168,6 +168,28 @@ def test_bench_two_ranks_gloo_rehearsal_verifies_gathered_frame():
     assert res["n_gpus"] == 2 and res["verified"] is True and res["value"] > 0 and res["scaling"] == "strong"
 
 
+def test_bench_single_gpu_contract_line():
+    """bench.py at N = 1 (small frame, few steps): ONE JSON line with the contract's keys, the roofline and CPU-baseline
+    objects, a verified frame, and per-launch kernel times that are consistent with the step time."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--verify", "--width", "480", "--height", "272",
+                                   "--no-cpu-baseline"], cwd=root, text=True, stderr=subprocess.DEVNULL, timeout=600)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 12 and r["warmup"] == 3 and r["unit"] == "Msamples/s" and r["higher_is_better"] is True
+    assert r["verified"] is True and r["vs_baseline"] is None and r["dtype"] == "f32" and "workload" in r["config"]
+    rf = r["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["frames_per_launch"] == 6.0 and rf["kernel_avg_ms"] > 0
+    assert abs(r["value"] - 480 * 272 * 4 / (r["ms_per_step"] * 1e-3) / 1e6) / r["value"] < 1e-2
+
+
 def test_prebuilt_bvh_files_roundtrip(rt, orc, gpu_ctx, tmp_path):
     """configs C2/C3 name data/BVH2.bin and data/BVH4_wide.bin: dump, reload into a fresh context, render the same."""
     tris = rt.procedural_scene(0, 20000)
