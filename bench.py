@@ -157,9 +157,22 @@ def main():
     # Frames are submitted in batches: the library traces `batch` consecutive frames with one persistent
     # launch (pt_set_batch), which amortises the sparse tail of a frame -- essential for the small per-GPU
     # shares of a sharded run.  The RCCL gather then moves one batch at a time (fewer, larger collectives).
-    # At least two launches per timed region so that consecutive launches overlap (measured: tools/tune16.sh).
+    # At least two launches per timed region so that consecutive launches overlap (measured: tools/sweeps/tune16.sh); up to 32
+    # frames of work per launch (256 frames = pt_set_batch's maximum).  A sharded run gathers batch b while batch b+1 traces, so
+    # its LAST gather is exposed: its launches shrink towards the end (128, 64, 32, 16, 8, 8 for 256 steps on 8 GPUs).
     batch = int(os.environ.get("PT_BENCH_BATCH", "0")) or (args.steps + 1) // 2
-    batch = max(1, min(32, batch))   # 32 = pt_set_batch's maximum
+    batch = max(1, min(32 * world, 256, batch))
+
+    def schedule(n_steps):
+        """[(first step, frames)] of the launches that cover n_steps."""
+        out, done = [], 0
+        while done < n_steps:
+            left = n_steps - done
+            b = min(batch, left)
+            if world > 1 and not os.environ.get("PT_BENCH_BATCH"):
+                b = min(b, max(8, left // 2), left)
+            out.append((done, b)); done += b
+        return out
     ctx.set_batch(1)
     if sharded:
         stride = max(rt.tile_layout(width, height, r, world)[1] for r in range(world))
@@ -197,7 +210,7 @@ def main():
         work.wait()
         if rank == 0:
             if host_stage:
-                gathered[slot].copy_(torch.stack(work.cpu_list))
+                gathered[slot][:, :nf].copy_(torch.stack(work.cpu_list))
             for j in range(nf):          # rank r's buffer of frame j sits at gathered[slot][r][j]
                 ctx.deinterleave(gathered[slot].data_ptr() + j * stride * 4, batch * stride, width, height, world)
 
@@ -211,50 +224,42 @@ def main():
         def wait(self):
             pass
 
-    def ship(slot, nf):              # the batch in compact[slot] has been launched: gather it, finish the previous one
+    def ship(slot, nf):              # the launch in compact[slot][:nf] has been submitted: gather it, finish the previous one
         if host_stage:
-            work = _HostWork(compact[slot])
+            work = _HostWork(compact[slot][:nf])
         else:
-            glist = [gathered[slot][r] for r in range(world)] if rank == 0 else None
-            work = dist.gather(compact[slot], glist, dst=0, async_op=True)
-        finish(pending[0])               # gather(b-1) has had the whole batch b to complete
+            glist = [gathered[slot][r][:nf] for r in range(world)] if rank == 0 else None
+            work = dist.gather(compact[slot][:nf], glist, dst=0, async_op=True)
+        finish(pending[0])               # gather(b-1) has had the whole launch b to complete
         pending[0] = (work, slot, nf)
 
-    def step(i, p):                  # called with `stream` current
-        if not sharded:
-            ctx.set_output_buffer(frames_out[i % (2 * batch)].data_ptr(), height * width * 4)
-            ctx.render(p)
-            return
-        b, j = divmod(i, batch)
-        ctx.set_compact_buffer(compact[b & 1][j].data_ptr(), stride)
-        ctx.render(p)                    # the library launches the batch with its last frame
-        if j == batch - 1:
-            ship(b & 1, batch)
-
-    def drain(n_steps):
-        ctx.flush()                      # a partially filled last batch
-        if sharded and n_steps % batch:
-            ship((n_steps // batch) & 1, n_steps % batch)
+    def run(n_steps, first_frame, p):    # called with `stream` current: n_steps frames as the launches of schedule()
+        for k, (first, nf) in enumerate(schedule(n_steps)):
+            for j in range(nf):
+                p.frame = first_frame + first + j
+                if sharded:
+                    ctx.set_compact_buffer(compact[k & 1][j].data_ptr(), stride)
+                else:
+                    ctx.set_output_buffer(frames_out[(k & 1) * batch + j].data_ptr(), height * width * 4)
+                ctx.render(p)                # the library launches a full batch with its last frame ...
+            if nf < batch:
+                ctx.flush()                  # ... and a shorter one here (the slots stay sized for `batch` frames)
+            if sharded:
+                ship(k & 1, nf)
         if sharded:
             finish(pending[0])
             pending[0] = None
 
     p = params()
     with torch.cuda.stream(stream):
-        for i in range(args.warmup):
-            p.frame = args.steps + i
-            step(i, p)
-        drain(args.warmup)
+        run(args.warmup, args.steps, p)
     if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     ctx.timing_begin(args.steps)
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
-        for i in range(args.steps):
-            p.frame = i
-            step(i, p)
-        drain(args.steps)
+        run(args.steps, 0, p)
     torch.cuda.synchronize()
     if sharded:
         dist.barrier()
@@ -307,7 +312,7 @@ def main():
                          "kernel": "trace_paths_kernel (persistent megakernel)", "kernel_avg_ms": round(k_avg_ms, 4),
                          "frames_per_launch": frames_per_launch,
                          "note": "algorithmic bytes (reference record sizes x records examined) over the per-launch duration by hipEvents on the launch stream; "
-                                 "a launch traces %d frames and consecutive launches overlap on side streams; the scene is cache resident, so the algorithmic rate "
+                                 "a launch traces up to %d frames and consecutive launches overlap on side streams; the scene is cache resident, so the algorithmic rate "
                                  "may exceed the HBM peak -- see traffic" % batch,
                          "achieved_from_throughput": round(my_bytes * args.steps / elapsed / 1e9, 2),
                          "algorithmic_bytes_per_frame": int(my_bytes), "algorithmic_bytes_per_frame_min_max": [int(min(frame_bytes)), int(max(frame_bytes))],

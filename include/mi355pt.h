@@ -157,7 +157,7 @@ int pt_scene_info(PtContext* ctx, uint32_t* num_tris, uint32_t* num_nodes2, uint
 /* PathTracer.render() compute pass (PathTracer.js:756-802 + renderer.wgsl:355-413).
  * Asynchronous on the context's stream; results are read with pt_read_radiance. */
 int pt_render(PtContext* ctx, const PtRenderParams* params);
-/* Batched submission (PT_MODE_PATH): queue `frames_per_launch` (1..32, default 1) consecutive pt_render calls of
+/* Batched submission (PT_MODE_PATH): queue `frames_per_launch` (1..256, default 1) consecutive pt_render calls of
  * the same shape and trace them with ONE persistent launch -- small frames (e.g. a 1/8 tile share of a
  * multi-GPU run) then fill the chip like a whole frame does.  A partial batch is launched by whatever
  * needs its result: pt_synchronize, any read-back, pt_compact_radiance / pt_deinterleave, scene changes.

@@ -67,12 +67,14 @@ struct PtContext {
     struct FrameSlot {
         hipStream_t side = nullptr; hipEvent_t resolved = nullptr, done = nullptr; bool used = false;
         DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<float4> cont; DevBuf<uint32_t> flags;
+        DevBuf<ptk::FrameParams> frame_params; DevBuf<float4*> frame_outs;      // per-frame parameters / targets of the launch in this slot
         const void* primed_ptr = nullptr; size_t primed_samples = 0;   // what the resident prefill covers
     };
     static constexpr int kMaxSlots = 16;
     FrameSlot slots[kMaxSlots]; int num_slots = 0; uint32_t next_slot = 0;
     // frames queued for one batched launch (pt_set_batch): launched when full or when anything needs their result
     uint32_t batch_size = 1; uint32_t pending = 0; ptk::RenderArgs pendingA; bool pending_ring = false; uint32_t pending_rank = 0, pending_count = 1;
+    std::vector<ptk::FrameParams> pending_frames; std::vector<float4*> pending_outs;
     DevBuf<unsigned long long> d_wave_times; uint32_t wave_times_n = 0;
     int num_cus = 0;
     DevBuf<unsigned long long> d_stats;
@@ -205,6 +207,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         PT_HIP(ctx, s.spill.ensure(size_t(full_lanes) * size_t(64 - PT_SHORT_STACK)));
         PT_HIP(ctx, s.cont.ensure(A.cont_passes ? size_t(A.pool_capacity) * 4u * 2u : 4u));
         PT_HIP(ctx, s.flags.ensure(A.cont_passes ? size_t(A.pool_capacity) * 2u : 4u));
+        PT_HIP(ctx, s.frame_params.ensure(std::max<size_t>(ctx->batch_size, nf))); PT_HIP(ctx, s.frame_outs.ensure(std::max<size_t>(ctx->batch_size, nf)));
         if (s.primed_ptr != (const void*)s.samples.ptr || s.primed_samples < cap_samples) {
             if (s.used) PT_HIP(ctx, hipStreamWaitEvent(s.side, s.resolved, 0));
             PT_HIP(ctx, ptk::launch_prime(s.queue.ptr, s.samples.ptr, uint32_t(cap_samples), s.side));
@@ -225,6 +228,18 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     // lets consecutive frames overlap); the resolve on the main stream waits for the trace.
     if (!ring) PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
     if (sl.used) PT_HIP(ctx, hipStreamWaitEvent(sl.side, sl.resolved, 0));
+    {   // per-frame parameters and targets into the slot's device arrays; a frame whose target a later frame of this launch
+        // overwrites is marked (its result would not survive one-launch-per-frame rendering either)
+        std::vector<ptk::FrameParams>& F = ctx->pending_frames;
+        for (uint32_t i = 0; i < nf; ++i) {
+            bool superseded = false;
+            if ((F[i].accum_mode & 0xffu) == 0u)
+                for (uint32_t g = i + 1u; g < nf && !superseded; ++g) superseded = ctx->pending_outs[g] == ctx->pending_outs[i];
+            F[i].accum_mode = (F[i].accum_mode & 0xffu) | (superseded ? 0x100u : 0u);
+        }
+        PT_HIP(ctx, ptk::launch_frame_params(F.data(), ctx->pending_outs.data(), nf, sl.frame_params.ptr, sl.frame_outs.ptr, sl.side));
+        A.frames = sl.frame_params.ptr; A.outs = sl.frame_outs.ptr;
+    }
     // timing ring: events tightly around the trace kernels on the stream they run on
     PT_HIP(ctx, ptk::launch_trace(A, stats, grid, sl.side, ring ? e0 : nullptr, ring ? e1 : nullptr));
     PT_HIP(ctx, hipEventRecord(sl.done, sl.side));
@@ -296,7 +311,7 @@ void pt_destroy(PtContext* ctx) {
     ctx->d_subtree.release(); ctx->d_ids.release(); ctx->d_bnd.release(); ctx->d_child_pos.release(); ctx->d_build_temp.release();
     if (ctx->h_word) (void)hipHostFree(ctx->h_word);
     for (auto& sl : ctx->slots) {
-        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.cont.release(); sl.flags.release();
+        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.cont.release(); sl.flags.release(); sl.frame_params.release(); sl.frame_outs.release();
         if (sl.resolved) (void)hipEventDestroy(sl.resolved);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.side) { (void)hipStreamSynchronize(sl.side); (void)hipStreamDestroy(sl.side); }
@@ -694,7 +709,8 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
             if (!same || ctx->pending >= PT_MAX_BATCH) { if (int rc = flush_pending(ctx)) return rc; }
         }
         if (!ctx->pending) { ctx->pendingA = A; ctx->pending_ring = false; ctx->pending_rank = p->tile_rank; ctx->pending_count = count; }
-        ctx->pendingA.frames[ctx->pending] = fp; ctx->pendingA.outs[ctx->pending] = A.out;
+        if (ctx->pending == 0) { ctx->pending_frames.clear(); ctx->pending_outs.clear(); }
+        ctx->pending_frames.push_back(fp); ctx->pending_outs.push_back(A.out);
         ++ctx->pending;
         ctx->timed = false;
         if (stats || ctx->pending >= ctx->batch_size) return flush_pending_stats(ctx, stats, sharded, count);
@@ -713,7 +729,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
 int pt_set_batch(PtContext* ctx, uint32_t frames_per_launch) {
     if (int rc = bind(ctx)) return rc;
     if (int rc = flush_pending(ctx)) return rc;
-    if (frames_per_launch < 1u || frames_per_launch > PT_MAX_BATCH) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_batch: 1..32 frames per launch");
+    if (frames_per_launch < 1u || frames_per_launch > PT_MAX_BATCH) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_batch: 1..256 frames per launch");
     ctx->batch_size = frames_per_launch;
     return PT_OK;
 }

@@ -38,14 +38,17 @@
 
 namespace ptk {
 
-#define PT_MAX_BATCH 32     // frames per persistent launch (FrameParams + out pointer: 56 B of kernarg each)
+#define PT_MAX_BATCH 256    // frames per persistent launch (their per-frame parameters live in a small device array)
 // Per-frame part of the UBO for a batched launch (several consecutive frames traced by one persistent launch).
 struct FrameParams {
     float cam[3]; float focal;
     float quat[4];
     float aspect; uint32_t frame; uint32_t seed;
-    uint32_t accum_mode;        // 0: no accumulation buffer, 1: restart the running sum, 2: add to it
+    uint32_t accum_mode;        // bits 0..7: 0 no accumulation buffer, 1 restart the running sum, 2 add to it;
+                                // bit 8: a later frame of the same launch has the same output target (this frame's result is not kept)
 };
+constexpr int kFrameChunk = 32; // frames per upload kernel (their parameters travel as that kernel's argument)
+struct FrameChunk { FrameParams f[kFrameChunk]; float4* o[kFrameChunk]; };
 
 // Passed by value as the kernel argument (lives in SGPRs / the kernarg segment).
 struct RenderArgs {
@@ -89,7 +92,7 @@ struct RenderArgs {
     uint32_t  pool_capacity, flush_threshold, cont_passes;
     uint32_t  shade_threshold, fill_threshold, leaf_threshold;
     // batched launch: frames[i] / outs[i] for i < num_frames; items of frame i are batches [i*batches_per_frame, ...)
-    FrameParams frames[PT_MAX_BATCH]; float4* outs[PT_MAX_BATCH];
+    const FrameParams* frames; float4* const* outs;     // device arrays of the frame slot, filled by launch_frame_params
     uint32_t  num_frames, batches_per_frame;
     uint32_t  prime;            // 1: launch_trace must zero the control block and prefill the samples itself
 };
@@ -98,6 +101,8 @@ hipError_t launch_render(const RenderArgs& args, int kmode, bool stats, hipStrea
 // k0/k1 (optional): events recorded immediately around the trace_paths_kernel launches
 hipError_t launch_trace(const RenderArgs& args, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1);
 hipError_t launch_prime(uint32_t* queue, float4* samples, uint32_t n_samples, hipStream_t stream);   // first use of a frame slot
+// per-frame parameters and output targets of a launch into the slot's device arrays (asynchronous: the data travels as kernel arguments)
+hipError_t launch_frame_params(const FrameParams* frames, float4* const* outs, uint32_t n, FrameParams* d_frames, float4** d_outs, hipStream_t stream);
 hipError_t launch_resolve(const RenderArgs& args, hipStream_t stream);
 uint32_t megakernel_grid(int num_cus);
 uint32_t megakernel_block();

@@ -67,8 +67,8 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
     }
     const uint32_t total_items = CONT ? in_count : A.total_items;
     const bool pool_on = A.flush_threshold != 0u;
-    // per-frame parameters are read through the kernarg segment (per-lane index: lanes of one refill may straddle two frames)
-    const FrameParams* const frames = (const FrameParams*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(RenderArgs, frames));
+    // per-frame parameters: a small device array (per-lane index: lanes of one refill may straddle two frames)
+    const FrameParams* const frames = A.frames;
     const uint32_t chunk_items = CONT ? 64u : A.chunk_items;
     // the XCD this wavefront runs on (HW_REG_XCC_ID, bits 3:0) and how many other XCDs' ranges it has moved on to
     const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
@@ -428,8 +428,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
     const size_t out_index = A.compact ? (size_t)idx : ((size_t)py * A.width + px);
     const float bg = 0.0f + 1.0f * kBgPrimary;
     const float4 prime = make_float4(bg, bg, bg, 1.0f);
-    const FrameParams* const frames = (const FrameParams*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(RenderArgs, frames));
-    float4* const* const outs = (float4* const*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(RenderArgs, outs));
+    const FrameParams* const frames = A.frames;
+    float4* const* const outs = A.outs;
     const uint32_t f_begin = ACCUM ? 0u : blockIdx.y, f_end = ACCUM ? A.num_frames : blockIdx.y + 1u;
     for (uint32_t fid = f_begin; fid < f_end; ++fid) {
         F3 sum = f3(0.0f, 0.0f, 0.0f);
@@ -437,9 +437,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
         if (!ACCUM) {
             // independent frames resolve in parallel; where several share one output target the last submitted one is the
             // result (what resolving them in order would leave), the others only hand their sample slots back
-            bool superseded = false;
-            for (uint32_t g = fid + 1u; g < A.num_frames; ++g) superseded |= (outs[g] == outs[fid]);
-            if (superseded) {
+            if (frames[fid].accum_mode & 0x100u) {
                 for (uint32_t s = 0; s < A.spp; ++s) sp[(size_t)s * 64u] = prime;
                 continue;
             }
@@ -456,7 +454,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
         }
         float count = (float)A.spp;
         if (ACCUM) {
-            const uint32_t am = frames[fid].accum_mode;
+            const uint32_t am = frames[fid].accum_mode & 0xffu;
             const float4 acc = (am == 2u) ? A.accum[out_index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             sum = f3(acc.x + sum.x, acc.y + sum.y, acc.z + sum.z);
             count = acc.w + count;
@@ -530,6 +528,23 @@ hipError_t launch_resolve(const RenderArgs& A, hipStream_t stream) {
     if (A.accum) hipLaunchKernelGGL(resolve_kernel<true>, dim3((n + 255u) / 256u, 1), dim3(256), 0, stream, A);
     else         hipLaunchKernelGGL(resolve_kernel<false>, dim3((n + 255u) / 256u, A.num_frames), dim3(256), 0, stream, A);
     return hipGetLastError();
+}
+
+__global__ void write_frame_params_kernel(const FrameChunk c, FrameParams* d_frames, float4** d_outs, uint32_t offset, uint32_t n) {
+    const uint32_t i = threadIdx.x;
+    if (i < n) { d_frames[offset + i] = c.f[i]; d_outs[offset + i] = c.o[i]; }
+}
+
+hipError_t launch_frame_params(const FrameParams* frames, float4* const* outs, uint32_t n, FrameParams* d_frames, float4** d_outs, hipStream_t stream) {
+    for (uint32_t off = 0; off < n; off += (uint32_t)kFrameChunk) {
+        FrameChunk c;
+        const uint32_t m = n - off < (uint32_t)kFrameChunk ? n - off : (uint32_t)kFrameChunk;
+        for (uint32_t i = 0; i < m; ++i) { c.f[i] = frames[off + i]; c.o[i] = outs[off + i]; }
+        for (uint32_t i = m; i < (uint32_t)kFrameChunk; ++i) { c.f[i] = frames[off]; c.o[i] = nullptr; }
+        hipLaunchKernelGGL(write_frame_params_kernel, dim3(1), dim3(kFrameChunk), 0, stream, c, d_frames, d_outs, off, m);
+        const hipError_t e = hipGetLastError(); if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_prime(uint32_t* queue, float4* samples, uint32_t n_samples, hipStream_t stream) {

@@ -105,7 +105,7 @@ class PathTracer {
   setCameraQuaternion(x, y, z, w) { this.cameraQuaternion = [x, y, z, w]; } // :828
   setFrameCount(frameCount) { this.frameCount = frameCount; }               // :832
 
-  // queue `n` (1..32) consecutive render() calls into one persistent GPU launch; read-backs flush a partial batch
+  // queue `n` (1..256) consecutive render() calls into one persistent GPU launch; read-backs flush a partial batch
   setBatch(n) { native().setBatch(this.device, n); }
   flush() { native().flush(this.device); }
 

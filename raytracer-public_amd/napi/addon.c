@@ -297,7 +297,7 @@ static napi_value fn_render(napi_env env, napi_callback_info info) {          /*
     return NULL;
 }
 
-static napi_value fn_set_batch(napi_env env, napi_callback_info info) {       /* frames per persistent launch (1..32) */
+static napi_value fn_set_batch(napi_env env, napi_callback_info info) {       /* frames per persistent launch (1..256) */
     napi_value argv[2]; if (!get_args(env, info, 2, argv)) return NULL;
     PtContext* ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
     PT_CALL(ctx, pt_set_batch(ctx, get_u32(env, argv[1])), "pt_set_batch");

@@ -161,7 +161,7 @@ def test_bench_two_ranks_gloo_rehearsal_verifies_gathered_frame():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                                   "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--verify",
+                                   "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "3", "--verify",
                                    "--width", "640", "--height", "360"], env=env, cwd=root, text=True, stderr=subprocess.STDOUT, timeout=600)
     line = [l for l in out.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)

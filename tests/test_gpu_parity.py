@@ -352,7 +352,8 @@ def test_whole_frame_output_buffers_in_a_batch(rt, gpu_ctx):
 
 
 def test_largest_batch_accumulates_like_single_launches(rt, gpu_ctx):
-    """32 frames (the pt_set_batch maximum) in one launch, accumulated: the running sum is the one 32 launches give."""
+    """32 frames in one launch, accumulated: the running sum is the one 32 launches give; 70 independent frames in one launch
+    (more than two upload chunks of per-frame parameters) land in their own targets; more than 256 per launch is refused."""
     tris = rt.procedural_scene(0, 12000)
     gpu_ctx.set_triangles(tris)
     gpu_ctx.build_bvh()
@@ -367,8 +368,27 @@ def test_largest_batch_accumulates_like_single_launches(rt, gpu_ctx):
         return out
     a, b = run(1), run(32)
     assert same_bits(a, b)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    nf, floats = 70, w * h * 4
+    buf = C.c_void_p(); assert hip.hipMalloc(C.byref(buf), C.c_size_t(floats * 4 * nf)) == 0
+    def frame(f):
+        return gpu_ctx.make_params(w, h, (0.01 * f, 0, 2.5), (0, 0, 0, 1), mode=rt.PT_MODE_PATH, spp=1, max_bounces=3, seed=9, frame=f)
+    gpu_ctx.render(gpu_ctx.make_params(w, h, mode=rt.PT_MODE_REFERENCE))
+    gpu_ctx.set_batch(nf)
+    for f in range(nf):
+        gpu_ctx.set_output_buffer(buf.value + f * floats * 4, floats)
+        gpu_ctx.render(frame(f))
+    gpu_ctx.synchronize()
+    gpu_ctx.set_output_buffer(0, 0); gpu_ctx.set_batch(1)
+    got = np.zeros((nf, h, w, 4), np.float32)
+    assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), buf, C.c_size_t(floats * 4 * nf), 2) == 0
+    hip.hipFree(buf)
+    for f in (0, 31, 32, 63, 64, 69):
+        gpu_ctx.render(frame(f))
+        assert same_bits(got[f], gpu_ctx.read_radiance()), f
     with pytest.raises(rt.PtError):
-        gpu_ctx.set_batch(33)
+        gpu_ctx.set_batch(257)
 
 
 def test_too_many_samples_per_launch_is_rejected(rt, gpu_ctx):
