@@ -180,6 +180,10 @@ def main():
         gathered = [torch.zeros(world, batch, stride, dtype=torch.float32, device="cuda") for _ in range(2)] if rank == 0 else [None, None]
         host_stage = backend != "nccl"   # rehearsal path (gloo): stage through host memory
         torch.cuda.synchronize()         # the zero fills ran on torch's default stream; everything below uses the context's
+        if not host_stage:               # bring the RCCL communicator up before anything is timed (even with --warmup 0)
+            probe = torch.zeros(8, device="cuda")
+            dist.gather(probe, [torch.zeros(8, device="cuda") for _ in range(world)] if rank == 0 else None, dst=0)
+            torch.cuda.synchronize()
     else:
         # whole frames: every frame of a launch is delivered into its own device buffer (two launches' worth, used alternately),
         # so no frame's result is overwritten by a later frame of the same launch
