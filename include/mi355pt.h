@@ -193,13 +193,17 @@ int pt_tile_layout(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t
 int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats);
 /* Render tile-sharded frames straight into a caller-owned device buffer (e.g. a torch tensor
  * that is then handed to the RCCL gather) instead of the context's own compact buffer.
- * device_ptr = NULL restores the internal buffer.  `floats` is the buffer's capacity.  The buffer that is
- * current when a frame is submitted is that frame's target; it must outlive the frame's launch (pt_flush). */
+ * `floats` is the buffer's capacity.  The buffer that is current when a frame is submitted is that frame's
+ * target, also for frames still queued by pt_set_batch when the target changes.  Lifetime rule: a buffer
+ * handed in here must stay allocated until a pt_synchronize (or any read-back) issued after the last frame
+ * that was submitted while it was current has returned.  device_ptr = NULL restores the internal buffer and
+ * launches whatever is still queued for caller-owned targets (it does not wait for it). */
 int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
 /* The same for whole frames (tile_count <= 1): render into a caller-owned row-major f32 RGBA device buffer of at least
  * width*height*4 floats instead of the context's own frame buffer, e.g. one buffer per frame of a batched launch so that
  * every frame stays available (frames of one launch that share a target leave only the last one's result, exactly as if they
- * had been rendered one after the other).  The read-backs read the target of the last frame.  NULL restores the internal buffer. */
+ * had been rendered one after the other).  The read-backs read the target of the last frame.  Same lifetime rule as
+ * pt_set_compact_buffer; NULL restores the internal buffer and launches what is still queued. */
 int pt_set_output_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
 /* Rank 0: scatter `tile_count` gathered compact buffers (device memory, concatenated in rank
  * order, each padded to `stride_floats`) into the context's full-frame radiance buffer. */

@@ -275,6 +275,10 @@ class Context:
         self._ck(lib.pt_timing_collect(self.h, _p(ms, C.c_float), C.c_uint32(capacity), C.byref(n)))
         return ms[: n.value].copy()
 
+    def debug_set_tune(self, name, value=None):
+        """Diagnostics: override one launch heuristic of the megakernel on this context (None restores the default)."""
+        self._ck(lib.pt_debug_set_tune(self.h, name.encode(), C.c_uint32(0xFFFFFFFF if value is None else value)))
+
     def set_compact_buffer(self, device_ptr, floats):
         self._ck(lib.pt_set_compact_buffer(self.h, C.c_void_p(device_ptr), C.c_uint64(floats)))
 

@@ -34,8 +34,34 @@ struct DevBuf {
 
 } // namespace
 
+// Development overrides of the megakernel's launch heuristics.  kAuto = use the measured default for the launch at hand.
+// Read from PT_TUNE_* ONCE, when the context is created (a shipped library does not consult the environment per launch);
+// tests and tools/sweep.sh change them through pt_debug_set_tune.
+struct PtTune {
+    static constexpr uint32_t kAuto = 0xFFFFFFFFu;
+    uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto, leaf = kAuto,
+             flush = kAuto, passes = kAuto, slots = kAuto;
+    uint32_t* find(const char* name) {
+        static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
+            {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
+            {"FILL", &PtTune::fill}, {"LEAF", &PtTune::leaf}, {"FLUSH", &PtTune::flush}, {"PASSES", &PtTune::passes}, {"SLOTS", &PtTune::slots}};
+        for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
+        return nullptr;
+    }
+    void from_environment() {
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "LEAF", "FLUSH", "PASSES", "SLOTS"};
+        for (const char* n : names) {
+            const std::string key = std::string("PT_TUNE_") + n;
+            const char* v = std::getenv(key.c_str());
+            if (v && *v) *find(n) = uint32_t(std::strtoul(v, nullptr, 10));
+        }
+    }
+    static uint32_t pick(uint32_t knob, uint32_t dflt) { return knob == kAuto ? dflt : knob; }
+};
+
 struct PtContext {
     int device = 0;
+    PtTune tune;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -107,12 +133,6 @@ int bind(PtContext* ctx) {
     return PT_OK;
 }
 
-// development knob: integer override from the environment (defaults are the tuned values)
-uint32_t tune(const char* name, uint32_t dflt) {
-    const char* v = std::getenv(name);
-    return v && *v ? uint32_t(std::strtoul(v, nullptr, 10)) : dflt;
-}
-
 int upload_wide(PtContext* ctx, const uint32_t* bvh4, uint64_t words) {
     pt::WideBvh w; std::string err;
     if (!pt::build_wide_bvh(bvh4, words, w, err)) return fail(ctx, PT_ERR_BAD_BVH, err);
@@ -141,7 +161,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     // a tile-sharded frame is a fraction of the work: fewer, denser wavefronts (measured: 1/8 frame best at grid/4);
     // a batch of nf such frames is nf times the work again
     {
-        uint32_t div = tune("PT_TUNE_GRIDDIV", count >= 8u ? 4u : (count >= 2u ? 2u : 1u));
+        uint32_t div = PtTune::pick(ctx->tune.grid_div, count >= 8u ? 4u : (count >= 2u ? 2u : 1u));
         if (nf > 1u) div = div > nf ? div / nf : 1u;
         if (div > 1u) grid = (grid + div - 1u) / div;
     }
@@ -160,7 +180,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     // = balance when each wavefront only sees a few chunks).  Measured: tools/sweeps/tune20.sh .. tune22.sh.
     {
         const uint32_t work8_r = nf * 8u / (count ? count : 1u);
-        A.perm_rows = tune("PT_TUNE_ROWS", work8_r >= 64u ? nf : (work8_r >= 8u ? 128u * nf : 64u * nf));
+        A.perm_rows = PtTune::pick(ctx->tune.rows, work8_r >= 64u ? nf : (work8_r >= 8u ? 128u * nf : 64u * nf));
     }
     if (A.perm_rows < 1u) A.perm_rows = 1u;
     if (A.perm_rows > 4096u) A.perm_rows = 4096u;
@@ -168,23 +188,30 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     A.perm_cols = (A.num_batches + A.perm_rows - 1u) / A.perm_rows;
     if (uint64_t(A.perm_cols) * A.perm_rows * 64ull > 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: batch too large (more than 2^32 items per launch)");
     A.total_items = A.perm_cols * A.perm_rows * 64u;
-    A.chunk_items = tune("PT_TUNE_CHUNK", 512u);
+    A.chunk_items = PtTune::pick(ctx->tune.chunk, 512u);
+    if (A.chunk_items < 64u) A.chunk_items = 64u;
+    // every wavefront adds chunk_items to a 32-bit cursor once more after it has found the queue dry (once per XCD range with
+    // the XCD-aware queue): the cursor must not wrap, or items would be handed out twice and the launch would never end
+    if (uint64_t(A.total_items) + uint64_t(grid_lanes / 64u + 1u) * A.chunk_items > 0xFFFFFFFFull) {
+        ctx->pending = 0;
+        return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: launch too large for the 32-bit work-queue cursor (more than 2^32 - grid * chunk items; lower spp, the resolution or the batch)");
+    }
     {   // XCD-aware queue for long launches: 8 ranges of the logical item order, one cursor per XCD (chunk aligned; 0 = one queue).
         // Measured (tools/sweeps/tune17.sh, tools/sweeps/tune18.sh): 32-frame launches +2..3.5 %, HBM fetch traffic halved (L2 hit rate 85 -> 91 %);
         // no gain at 8 frames of work, a loss for a single frame (the ranges are not equally heavy).
         const uint32_t per = (A.total_items + 7u) / 8u;
         const uint32_t work8_q = nf * 8u / (count ? count : 1u);
-        A.xcd_span = tune("PT_TUNE_XCD", work8_q >= 64u ? 1u : 0u) ? ((per + A.chunk_items - 1u) / A.chunk_items) * A.chunk_items : 0u;
+        A.xcd_span = PtTune::pick(ctx->tune.xcd, work8_q >= 64u ? 1u : 0u) ? ((per + A.chunk_items - 1u) / A.chunk_items) * A.chunk_items : 0u;
     }
-    A.shade_threshold = tune("PT_TUNE_SHADE", PT_SHADE_THRESHOLD); A.fill_threshold = tune("PT_TUNE_FILL", PT_FILL_THRESHOLD); A.leaf_threshold = tune("PT_TUNE_LEAF", PT_LEAF_THRESHOLD);
-    A.flush_threshold = tune("PT_TUNE_FLUSH", sharded ? 0u : PT_FLUSH_THRESHOLD);   // sharded frames are too small to profit from a second pass
-    A.cont_passes = tune("PT_TUNE_PASSES", PT_MAX_CONT_PASSES);
+    A.shade_threshold = PtTune::pick(ctx->tune.shade, PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD); A.leaf_threshold = PtTune::pick(ctx->tune.leaf, PT_LEAF_THRESHOLD);
+    A.flush_threshold = PtTune::pick(ctx->tune.flush, sharded ? 0u : PT_FLUSH_THRESHOLD);   // sharded frames are too small to profit from a second pass
+    A.cont_passes = PtTune::pick(ctx->tune.passes, PT_MAX_CONT_PASSES);
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
     // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
     // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small
     // sharded launches need several in flight to fill the chip.  Measured: tools/sweeps/tune13.sh, tools/sweeps/tune14.sh.
     const uint32_t work8 = nf * 8u / (count ? count : 1u);      // eighths of a whole frame
-    int want_slots = int(tune("PT_TUNE_SLOTS", work8 >= 64u ? 2u : (work8 >= 16u ? PT_FRAME_SLOTS : (work8 >= 8u ? (sharded ? 4u : PT_FRAME_SLOTS) : (sharded ? 8u : PT_FRAME_SLOTS)))));
+    int want_slots = int(PtTune::pick(ctx->tune.slots, work8 >= 64u ? 2u : (work8 >= 16u ? PT_FRAME_SLOTS : (work8 >= 8u ? (sharded ? 4u : PT_FRAME_SLOTS) : (sharded ? 8u : PT_FRAME_SLOTS)))));
     if (want_slots < 1) want_slots = 1;
     if (want_slots > PtContext::kMaxSlots) want_slots = PtContext::kMaxSlots;
     ctx->num_slots = want_slots;
@@ -217,17 +244,23 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(want_slots))];
     A.prime = stats ? 1u : 0u;                   // instrumented launches start from a freshly primed prefix
     A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr;
+    uint32_t stat_waves = 0;
     if (stats) {
-        const uint32_t waves = grid_lanes / 64u;
-        PT_HIP(ctx, ctx->d_wave_times.ensure(size_t(waves) * 16u));
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(waves) * 16u * 8u, ctx->stream));
-        A.wave_times = ctx->d_wave_times.ptr; ctx->wave_times_n = waves;
+        stat_waves = grid_lanes / 64u;
+        PT_HIP(ctx, ctx->d_wave_times.ensure(size_t(stat_waves) * 16u));
+        A.wave_times = ctx->d_wave_times.ptr; ctx->wave_times_n = stat_waves;
     }
     // Dependencies: scene uploads are host-synchronous, so the trace only has to wait for the resolve
     // that last read this slot's sample buffer (NOT for the previous frame's resolve -- that is what
     // lets consecutive frames overlap); the resolve on the main stream waits for the trace.
     if (!ring) PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
     if (sl.used) PT_HIP(ctx, hipStreamWaitEvent(sl.side, sl.resolved, 0));
+    if (stats) {
+        // the counter blocks are zeroed on the stream the instrumented kernel runs on, behind everything that stream still has
+        // to wait for; the previous reader (pt_get_stats / pt_debug_*) copied them synchronously
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(unsigned long long), sl.side));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(stat_waves) * 16u * 8u, sl.side));
+    }
     {   // per-frame parameters and targets into the slot's device arrays; a frame whose target a later frame of this launch
         // overwrites is marked (its result would not survive one-launch-per-frame rendering either)
         std::vector<ptk::FrameParams>& F = ctx->pending_frames;
@@ -281,6 +314,7 @@ int pt_create(int device_ordinal, PtContext** out) {
     if (e != hipSuccess) return fail_hip(nullptr, e, "hipSetDevice");
     PtContext* ctx = new PtContext();
     ctx->device = dev;
+    ctx->tune.from_environment();
     {   // the context's stream carries the short resolve passes: highest priority, so their blocks are placed ahead of
         // the persistent trace launches (normal-priority side streams) whenever CU slots free up
         int lo = 0, hi = 0;
@@ -686,8 +720,12 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     } else {
         ctx->accum_count = 0;
     }
+    const bool mega_path = p->mode == PT_MODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute;
     if (stats) {
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        if (!mega_path) {      // the megakernel zeroes the block itself, on the stream its trace runs on (flush_pending_stats)
+            if (int rc = flush_pending(ctx)) return rc;
+            PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        }
         A.stats = ctx->d_stats.ptr;
     }
     ctx->last_stats = stats;
@@ -788,6 +826,17 @@ int pt_get_stats(PtContext* ctx, PtStats* out) {
     return PT_OK;
 }
 
+/* diagnostics (not in the public header): override one launch heuristic of this context ("FLUSH", "PASSES", "SLOTS", ...;
+ * value 0xFFFFFFFF restores the measured default).  Launches the open batch first. */
+int pt_debug_set_tune(PtContext* ctx, const char* name, uint32_t value) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
+    uint32_t* knob = name ? ctx->tune.find(name) : nullptr;
+    if (!knob) return fail(ctx, PT_ERR_INVALID_ARG, "pt_debug_set_tune: unknown knob");
+    *knob = value;
+    return PT_OK;
+}
+
 /* diagnostics (not in the public header): raw counter block of the last STATS launch */
 int pt_debug_counters(PtContext* ctx, unsigned long long* dst16) {
     if (int rc = bind(ctx)) return rc;
@@ -844,6 +893,7 @@ int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t ds
 
 int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats) {
     if (int rc = bind(ctx)) return rc;
+    if (!device_ptr) { if (int rc = flush_pending(ctx)) return rc; }    // frames queued for the caller's buffers are launched before the caller is told "no longer yours to keep"
     ctx->ext_compact = (float4*)device_ptr;
     ctx->ext_compact_floats = device_ptr ? floats : 0;
     return PT_OK;
@@ -851,6 +901,7 @@ int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats) {
 
 int pt_set_output_buffer(PtContext* ctx, void* device_ptr, uint64_t floats) {
     if (int rc = bind(ctx)) return rc;
+    if (!device_ptr) { if (int rc = flush_pending(ctx)) return rc; }
     ctx->ext_out = (float4*)device_ptr;
     ctx->ext_out_floats = device_ptr ? floats : 0;
     return PT_OK;

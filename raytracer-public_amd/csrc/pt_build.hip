@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void wide_nodes_kernel(const uint32_t* __restr
         if (c == kInvalidRef || c >= m) continue;
         const uint32_t* cr = bvh4 + 1 + (size_t)c * 8;
         const uint32_t w0 = cr[0], w1 = cr[1], w2 = cr[2];
-        if (box_degenerate(w0, w1, w2)) continue;
+        if (box_degenerate(w0, w1, w2)) { ref[s] = kDegenerateRef; continue; }   // fetched by the reference, entered by no ray
         box[3 * s] = w0; box[3 * s + 1] = w1; box[3 * s + 2] = w2;
         ref[s] = (cr[7] & kLeaf) ? (kLeaf | (cr[7] & 0x7fffffffu)) : wide_index[c];
     }

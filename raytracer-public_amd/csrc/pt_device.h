@@ -37,6 +37,7 @@ constexpr float kInfT = 1e30f;          // renderer.wgsl:64
 constexpr float kTriEps = 1e-7f;        // renderer.wgsl:178
 constexpr uint32_t kLeaf = 0x80000000u;
 constexpr uint32_t kInvalidRef = 0xFFFFFFFFu;
+constexpr uint32_t kDegenerateRef = 0xFFFFFFFEu;   // child slot whose record the reference fetches and rejects (renderer.wgsl:289-291): counted, never entered
 constexpr int kStackMax = 64;           // renderer.wgsl:8
 
 struct Ray { F3 o, d, inv; };

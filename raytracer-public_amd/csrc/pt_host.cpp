@@ -275,7 +275,7 @@ bool build_wide_bvh(const uint32_t* bvh4, uint64_t words, WideBvh& out, std::str
             wn.ref[s] = kInvalid;
             if (c == kInvalid || c >= m) continue;
             const uint32_t* cr = rec(c);
-            if (box_degenerate(cr[0], cr[1], cr[2])) continue;   // renderer.wgsl:291
+            if (box_degenerate(cr[0], cr[1], cr[2])) { wn.ref[s] = kDegenerate; continue; }   // renderer.wgsl:291: fetched, then skipped
             wn.box[s][0] = cr[0]; wn.box[s][1] = cr[1]; wn.box[s][2] = cr[2];
             wn.ref[s] = (cr[7] & kLeafFlag) ? (kLeafFlag | (cr[7] & 0x7fffffffu)) : wide_index[c];
         }

@@ -10,6 +10,7 @@ constexpr uint32_t kNode2Stride = 6;            // BVHBuilder.wgsl:5
 constexpr uint32_t kNode4Stride = 8;            // renderer.wgsl:10
 constexpr uint32_t kLeafFlag    = 0x80000000u;  // renderer.wgsl:11
 constexpr uint32_t kInvalid     = 0xFFFFFFFFu;  // renderer.wgsl:12
+constexpr uint32_t kDegenerate  = 0xFFFFFFFEu;  // wide layout only: a child the reference fetches and then rejects for every ray (renderer.wgsl:291)
 
 // ---- f16 codec -------------------------------------------------------------------
 float    half_to_float(uint32_t h);             // exact widening (PathTracer.js:16-40)
@@ -27,7 +28,7 @@ bool promote_to_bvh4_wide(const uint32_t* bvh2, uint64_t words, std::vector<uint
 // (3 words each, reference packing) followed by four child references.
 struct WideNode {
     uint32_t box[4][3];
-    uint32_t ref[4];   // kInvalid = empty slot; kLeafFlag|tri = leaf; else index of a WideNode
+    uint32_t ref[4];   // kInvalid = empty slot; kDegenerate = examined, never entered; kLeafFlag|tri = leaf; else index of a WideNode
 };
 static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 
@@ -39,8 +40,10 @@ struct WideBvh {
     uint32_t num_nodes4 = 0;
 };
 // Validates the reference-layout BVH4 and builds the wide layout.  Rejects: short buffer,
-// child reachable twice / cycles.  Children that the reference skips for every ray
-// (INVALID, index >= numNodes, degenerate box: renderer.wgsl:288-291) become empty slots.
+// child reachable twice / cycles.  Children that the reference skips for every ray without
+// fetching them (INVALID, index >= numNodes: renderer.wgsl:288) become empty slots; a child with a
+// degenerate box (fetched, then rejected: renderer.wgsl:289-291) becomes a kDegenerate slot, which
+// no ray enters but which counts as an examined record, exactly as in the reference.
 bool build_wide_bvh(const uint32_t* bvh4, uint64_t words, WideBvh& out, std::string& err);
 
 // 48-byte triangle record: v0, e1 = v1-v0, e2 = v2-v0, n = normalize(cross(e1,e2)) -- the same

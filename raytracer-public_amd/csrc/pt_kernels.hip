@@ -27,8 +27,9 @@ template <bool ANYHIT, bool STATS>
 __device__ __forceinline__ bool traverse(const RenderArgs& A, const Ray& r, float& best_t, uint32_t& best_tri,
                                          uint2* __restrict__ stk, Counters& cnt) {
     best_t = kInfT; best_tri = kInvalidRef;
-    if (A.root_ref == kInvalidRef || A.num_tris == 0u || A.root_degenerate) return false;
-    if (STATS) { cnt.nodes += 1; if (cnt.maxstack < 1u) cnt.maxstack = 1u; }
+    if (A.root_ref == kInvalidRef || A.num_tris == 0u) return false;
+    if (STATS) { cnt.nodes += 1; if (cnt.maxstack < 1u) cnt.maxstack = 1u; }   // the root record is fetched before its degenerate check (renderer.wgsl:240-244)
+    if (A.root_degenerate) return false;
     float troot;
     if (!slab(r, A.root_box[0], A.root_box[1], A.root_box[2], best_t, troot)) return false;
     uint32_t cur = A.root_ref;
@@ -66,10 +67,10 @@ __device__ __forceinline__ bool traverse(const RenderArgs& A, const Ray& r, floa
             const uint4* np = A.nodes + (size_t)cur * 4;
             const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             float t0, t1, t2, t3;
-            const bool h0 = (n3.x != kInvalidRef) && slab(r, n0.x, n0.y, n0.z, best_t, t0);
-            const bool h1 = (n3.y != kInvalidRef) && slab(r, n0.w, n1.x, n1.y, best_t, t1);
-            const bool h2 = (n3.z != kInvalidRef) && slab(r, n1.z, n1.w, n2.x, best_t, t2);
-            const bool h3 = (n3.w != kInvalidRef) && slab(r, n2.y, n2.z, n2.w, best_t, t3);
+            const bool h0 = (n3.x < kDegenerateRef) && slab(r, n0.x, n0.y, n0.z, best_t, t0);
+            const bool h1 = (n3.y < kDegenerateRef) && slab(r, n0.w, n1.x, n1.y, best_t, t1);
+            const bool h2 = (n3.z < kDegenerateRef) && slab(r, n1.z, n1.w, n2.x, best_t, t2);
+            const bool h3 = (n3.w < kDegenerateRef) && slab(r, n2.y, n2.z, n2.w, best_t, t3);
             if (STATS) cnt.nodes += (n3.x != kInvalidRef) + (n3.y != kInvalidRef) + (n3.z != kInvalidRef) + (n3.w != kInvalidRef);
             // nearest = first minimum in slot order (renderer.wgsl:315-318); first = first hit
             int nslot = -1, fslot = -1; float tn = kInfT, tf = 0.0f; uint32_t rn = kInvalidRef, rf = kInvalidRef;

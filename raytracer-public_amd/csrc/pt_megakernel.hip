@@ -54,7 +54,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
     const F3 base = f3(0.9f, 0.7f, 0.3f);
     const F3 L = light_dir();
     const F3 invL = safe_inv(L);
-    const bool scene_empty = (A.root_ref == kInvalidRef) || (A.num_tris == 0u) || (A.root_degenerate != 0u);
+    const bool scene_empty = (A.root_ref == kInvalidRef) || (A.num_tris == 0u);
 
     unsigned long long t_begin = 0, t_qempty = 0;
     uint32_t n_iter = 0, n_shade = 0, n_fill = 0, n_iter_q = 0; unsigned long long cy_shade = 0, cy_fill = 0, cy_step = 0, cy_step_q = 0, cy_mark = 0; unsigned long long lanes_sum = 0, lanes_sum_q = 0, leaf_lanes = 0; uint32_t spill_ops = 0, push_ops = 0, push8_ops = 0, push12_ops = 0;
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
     auto begin_ray = [&]() -> bool {
         S.best_t = kInfT; S.best_tri = kInvalidRef; S.sp = 0;
         if (scene_empty) return false;
-        if (STATS) { c_nodes += 1; if (c_maxstack < 1u) c_maxstack = 1u; }
+        if (STATS) { c_nodes += 1; if (c_maxstack < 1u) c_maxstack = 1u; }   // the root record is fetched before its degenerate check (renderer.wgsl:240-244)
+        if (A.root_degenerate != 0u) return false;
         Ray r; r.o = S.o; r.d = S.d; r.inv = S.inv;
         float troot;
         if (!slab(r, A.root_box[0], A.root_box[1], A.root_box[2], kInfT, troot)) return false;
@@ -335,8 +336,9 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                 const bool s1 = slab(r, n0.w, n1.x, n1.y, S.best_t, t1);
                 const bool s2 = slab(r, n1.z, n1.w, n2.x, S.best_t, t2);
                 const bool s3 = slab(r, n2.y, n2.z, n2.w, S.best_t, t3);
-                const bool h0 = s0 & (n3.x != kInvalidRef), h1 = s1 & (n3.y != kInvalidRef);
-                const bool h2 = s2 & (n3.z != kInvalidRef), h3 = s3 & (n3.w != kInvalidRef);
+                // enterable slots: neither empty (kInvalidRef) nor a degenerate child (kDegenerateRef: counted below, never entered)
+                const bool h0 = s0 & (n3.x < kDegenerateRef), h1 = s1 & (n3.y < kDegenerateRef);
+                const bool h2 = s2 & (n3.z < kDegenerateRef), h3 = s3 & (n3.w < kDegenerateRef);
                 if (STATS) c_nodes += (n3.x != kInvalidRef) + (n3.y != kInvalidRef) + (n3.z != kInvalidRef) + (n3.w != kInvalidRef);
                 // Branch-free form of renderer.wgsl:314-342 for one lane.  Hit children keep slot order;
                 // the nearest (first minimum of tmin) is entered next and trades places with the first

@@ -128,6 +128,33 @@ class Oracle:
         assert rc == 0
         return img, ids, st.as_dict()
 
+    def render_mt(self, params, tris, bvh4, threads=None, band=8):
+        """The same render over `band`-row strips on several host threads (the C call releases the GIL; strips write
+        disjoint rows).  Returns (image, stats) -- the counters summed over the strips, max_stack as a maximum."""
+        from concurrent.futures import ThreadPoolExecutor
+        import copy
+        tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1)
+        bvh4 = np.ascontiguousarray(bvh4, dtype=np.uint32)
+        img = np.zeros((params.height, params.width, 4), np.float32)
+        threads = threads or max(1, min(16, os.cpu_count() or 1))
+        sy = max(1, params.step_y)
+        band = ((band + sy - 1) // sy) * sy          # strips start on the subsample grid
+        y0, y1 = params.y0, min(params.y1, params.height)
+        strips = [(y, min(y + band, y1)) for y in range(y0, y1, band)]
+
+        def work(strip):
+            p = Params.from_buffer_copy(params)
+            p.y0, p.y1 = strip
+            st = Stats()
+            rc = self.lib.orc_render(C.byref(p), _p(tris, C.c_float), _p(bvh4, C.c_uint32), _p(img, C.c_float), None, C.byref(st))
+            assert rc == 0
+            return st.as_dict()
+
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            parts = list(ex.map(work, strips))
+        total = {k: (max(d[k] for d in parts) if k == "max_stack" else sum(d[k] for d in parts)) for k in parts[0]}
+        return img, total
+
     def render_brute(self, params, tris, spheres):
         tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1)
         spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1)

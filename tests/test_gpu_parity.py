@@ -234,7 +234,7 @@ def test_sponza_class_interior_bit_exact(rt, orc, gpu_ctx):
     assert (ids != 0xFFFFFFFF).mean() > 0.9        # interior: nearly every camera ray hits
 
 
-def test_donation_and_continuation_passes_bit_exact(rt, gpu_ctx, monkeypatch):
+def test_donation_and_continuation_passes_bit_exact(rt, gpu_ctx):
     """The optional drain scheme (sparse wavefronts park at a ray boundary, donate their paths as 64 B records,
     continuation passes pick them up) changes scheduling only: the image and the counters stay the same."""
     tris = rt.procedural_scene(0, 60000)
@@ -244,7 +244,7 @@ def test_donation_and_continuation_passes_bit_exact(rt, gpu_ctx, monkeypatch):
     gpu_ctx.render(gpu_ctx.make_params(640, 360, stats=True, **kw))
     want = gpu_ctx.read_radiance().copy(); st0 = gpu_ctx.stats()
     for flush, passes in ((24, 1), (48, 2), (63, 3)):
-        monkeypatch.setenv("PT_TUNE_FLUSH", str(flush)); monkeypatch.setenv("PT_TUNE_PASSES", str(passes))
+        gpu_ctx.debug_set_tune("FLUSH", flush); gpu_ctx.debug_set_tune("PASSES", passes)
         gpu_ctx.render(gpu_ctx.make_params(640, 360, stats=True, **kw))
         got = gpu_ctx.read_radiance().copy(); st = gpu_ctx.stats()
         assert same_bits(got, want), (flush, passes)
@@ -252,7 +252,7 @@ def test_donation_and_continuation_passes_bit_exact(rt, gpu_ctx, monkeypatch):
             assert st[k] == st0[k], (k, flush, passes)
         gpu_ctx.render(gpu_ctx.make_params(640, 360, **kw))
         assert same_bits(gpu_ctx.read_radiance(), want)
-    monkeypatch.delenv("PT_TUNE_FLUSH"); monkeypatch.delenv("PT_TUNE_PASSES")
+    gpu_ctx.debug_set_tune("FLUSH"); gpu_ctx.debug_set_tune("PASSES")
 
 
 def test_batched_launch_equals_frame_by_frame(rt, gpu_ctx):
