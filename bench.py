@@ -9,88 +9,102 @@ triangles, the reference's dragon.glb is absent), native LBVH2 -> collapsed BVH4
 (src/main.js:12, PathTracer.js:761).  value = Msamples/s = W*H*spp*K / wall time of the K
 timed steps (max over ranks), scene already resident in HBM.
 
-N > 1 (one process per GPU, launched by torch.distributed.run): the frame is sharded by
-interleaved 8x8 pixel tiles (rank = (tx+ty) % N); each rank renders its tiles into a compact
-buffer, RCCL gathers the buffers on rank 0 over xGMI (torch.distributed backend "nccl"), rank 0
-de-interleaves them into the full frame.  The gather of frame i overlaps the render of frame
-i+1 (double-buffered).  Total work per step is fixed -> "scaling": "strong".
+N > 1: one process per GPU.  Under torch.distributed.run the ranks come from the environment; started
+plainly (`python bench.py --gpus N`) this process launches the N ranks itself -- as children, before anything has
+touched a GPU -- and exits with their status.  The frame is sharded by interleaved 8x8 pixel tiles
+(rank = (tx+ty) % N); each rank renders its tiles into a compact buffer, RCCL gathers the buffers on rank 0 over
+xGMI (torch.distributed backend "nccl"), rank 0 de-interleaves them into the full frame.  The gather of launch b
+overlaps the trace of launch b+1.  Total work per step is fixed -> "scaling": "strong".
+
+Every run checks one TIMED frame against the CPU oracle on a fixed pixel grid (every 16th pixel in x and y, all samples,
+bit for bit) and prints "verified": true; a mismatch ends the run with a non-zero status and no result line.
+
+The JSON line's `roofline` names the resource that bounds trace_paths_kernel (vector-instruction issue; DESIGN.md
+section 7), with the kernel's busy time measured live (union of the per-launch hipEvent intervals on the launch streams)
+and the per-frame counter totals taken from the rocprofv3 --pmc passes of THIS command committed under profiles/
+(tools/pmc_bench.sh).  The SURVEY 8d algorithmic byte rate is reported next to it, not as a fraction of a roof it does
+not touch: the scene is cache resident.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")   # before the HIP runtime initialises (overlapped frame slots)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 WIDTH, HEIGHT, SPP, BOUNCES, SEED = 1920, 1080, 4, 8, 1
 NUM_TRIS, SCENE_SEED = 871414, 20260109
-HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_NODE, BYTES_TRI, BYTES_SAMPLE = 32, 36, 16   # SURVEY.md section 8d
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction occupies its SIMD for 2 cycles, 2.4 GHz max clock;
+# L2 aggregate ~34.5 TB/s (128-byte lines); HBM3E 8 TB/s
+SIMDS, VALU_CYCLES_PER_WAVE_INST, CLOCK_HZ = 1024, 2.0, 2.4e9
+VALU_PEAK_GINST = SIMDS * CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST / 1e9
+L2_PEAK_GBS, L2_LINE, HBM_PEAK_GBS = 34500.0, 128, 8000.0
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
+KERNEL_SOURCES = ["pt_megakernel.hip", "pt_device.h", "pt_kernels.h"]
+VERIFY_STEP = 16
+
+
+def source_tag():
+    """Identifies the kernel build the PMC summary was taken from."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "raytracer-public_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(st):
     return BYTES_NODE * st["nodes_examined"] + BYTES_TRI * st["tris_tested"] + BYTES_SAMPLE * st["samples"]
 
 
-def cpu_baseline(tris, bvh4):
-    """The CPU oracle (a port of the same loop) on a bounded sample of the same workload:
-    the whole frame, single thread."""
+def load_oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc as orc_mod
-    orc = orc_mod.load()
+    return orc_mod, orc_mod.load()
+
+
+def cpu_baseline(tris, bvh4):
+    """The CPU oracle (a port of the same loop) on a bounded sample of the same workload: the whole frame, single thread."""
+    orc_mod, orc = load_oracle()
     p = orc.make_params(WIDTH, HEIGHT, NUM_TRIS, mode=orc_mod.MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED, step=(1, 1))
     t0 = time.time()
     _, _, st = orc.render(p, tris, bvh4)
     dt = time.time() - t0
     return {"value": round(st["samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
             "sample": "every pixel of the same 1920x1080/4spp/8-bounce frame (%d samples, %.1f s), oracle/pt_oracle.cpp single thread, %d host cores present"
-                      % (st["samples"], dt, os.cpu_count() or 0)}, st
+                      % (st["samples"], dt, os.cpu_count() or 0)}
 
 
 def cpu_baseline_threads(tris, bvh4):
-    """The same oracle over row bands on several host threads (ctypes releases the GIL; bands write disjoint rows), for
-    context: the whole frame again.  Thread count = the CPU share of a one-GPU box (16) or fewer."""
-    import ctypes as C
-    from concurrent.futures import ThreadPoolExecutor
-    import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import orc as orc_mod
-    orc = orc_mod.load()
+    """The same oracle over row bands on several host threads, for context: the whole frame again.
+    Thread count = the CPU share of a one-GPU box (16) or fewer."""
+    orc_mod, orc = load_oracle()
     threads = max(1, min(16, os.cpu_count() or 1))
-    tris = np.ascontiguousarray(tris, np.float32).reshape(-1); bvh4 = np.ascontiguousarray(bvh4, np.uint32)
-    img = np.zeros((HEIGHT, WIDTH, 4), np.float32)
-    bands = [(y, min(y + 8, HEIGHT)) for y in range(0, HEIGHT, 8)]          # 8-row bands, handed out dynamically
-
-    def work(band):
-        p = orc.make_params(WIDTH, HEIGHT, NUM_TRIS, mode=orc_mod.MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED, rect=(0, band[0], WIDTH, band[1]))
-        st = orc_mod.Stats()
-        rc = orc.lib.orc_render(C.byref(p), tris.ctypes.data_as(C.POINTER(C.c_float)), bvh4.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                img.ctypes.data_as(C.POINTER(C.c_float)), None, C.byref(st))
-        assert rc == 0
-        return st.samples
-
+    p = orc.make_params(WIDTH, HEIGHT, NUM_TRIS, mode=orc_mod.MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED)
     t0 = time.time()
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        samples = sum(ex.map(work, bands))
+    _, st = orc.render_mt(p, tris, bvh4, threads=threads)
     dt = time.time() - t0
-    return {"value": round(samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": "every pixel of the same frame in 8-row bands over %d host threads (%d samples, %.1f s), oracle/pt_oracle.cpp" % (threads, samples, dt)}
+    return {"value": round(st["samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": "every pixel of the same frame in 8-row bands over %d host threads (%d samples, %.1f s), oracle/pt_oracle.cpp" % (threads, st["samples"], dt)}
 
 
 def cpu_baseline_node(tris, bvh4):
     """The same loop as a single-thread Node/JS program (oracle/js/pt_oracle.js, bit-identical to the C++
     oracle): every 2nd pixel in x and y of the same frame."""
-    import shutil, subprocess, tempfile
+    import shutil, tempfile
     import numpy as np
     node = shutil.which("node")
     if node is None:
         return None
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import orc as orc_mod
+    orc_mod, _ = load_oracle()
     focal, aspect = orc_mod.focal_aspect(WIDTH, HEIGHT)
     with tempfile.TemporaryDirectory() as d:
         np.ascontiguousarray(tris, np.float32).tofile(os.path.join(d, "t")); np.ascontiguousarray(bvh4, np.uint32).tofile(os.path.join(d, "b"))
@@ -104,6 +118,46 @@ def cpu_baseline_node(tris, bvh4):
                       % (info["stats"]["samples"], info["seconds"], info["node"])}
 
 
+def schedule(n_steps, batch, world, fixed_batch):
+    """[(first step, frames)] of the launches that cover n_steps.  A sharded run gathers launch b while launch b+1 traces, so its
+    LAST gather is exposed: its launches shrink towards the end (128, 64, 32, 16, 8, 8 for 256 steps on 8 GPUs)."""
+    out, done = [], 0
+    while done < n_steps:
+        left = n_steps - done
+        b = min(batch, left)
+        if world > 1 and not fixed_batch:
+            b = min(b, max(8, left // 2), left)
+        out.append((done, b)); done += b
+    return out
+
+
+def busy_ms(starts, durs):
+    """Length of the union of the [start, start + dur] intervals."""
+    iv = sorted((float(s), float(s) + float(d)) for s, d in zip(starts, durs))
+    total, cur_a, cur_b = 0.0, None, None
+    for a, b in iv:
+        if cur_b is None or a > cur_b:
+            if cur_b is not None:
+                total += cur_b - cur_a
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    if cur_b is not None:
+        total += cur_b - cur_a
+    return total
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as children of a process that has not
+    touched the GPU (no exec of an initialised process) and hand their exit status on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,16 +166,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
-    ap.add_argument("--verify", action="store_true", help="rank 0: check the gathered frame bit-for-bit against a whole-frame render")
+    ap.add_argument("--verify", action="store_true", help="kept for compatibility: the check against the oracle always runs")
+    ap.add_argument("--no-reference-shape", action="store_true", help="skip the one-render()-per-frame figures")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world            # launched under torch.distributed.run: the launcher's rank count wins
 
     import torch                     # first: its HIP runtime is the one libmi355pt binds to
     import torch.distributed as dist
@@ -149,31 +205,23 @@ def main():
 
     # Every step is a NEW frame of the same camera (frame index i: a fresh sample set, as in a progressive render), so the
     # frames that share a batched launch do not trace identical rays.
-    def params(frame=0, stats=False):
+    def params(frame=0, stats=False, whole=False):
         return ctx.make_params(width, height, mode=rt.PT_MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED, frame=frame,
-                               tile_rank=rank, tile_count=world, stats=stats)
+                               tile_rank=0 if whole else rank, tile_count=1 if whole else world, stats=stats)
 
     sharded = world > 1
     # Frames are submitted in batches: the library traces `batch` consecutive frames with one persistent
     # launch (pt_set_batch), which amortises the sparse tail of a frame -- essential for the small per-GPU
     # shares of a sharded run.  The RCCL gather then moves one batch at a time (fewer, larger collectives).
-    # At least two launches per timed region so that consecutive launches overlap (measured: tools/sweeps/tune16.sh); up to 32
-    # frames of work per launch (256 frames = pt_set_batch's maximum).  A sharded run gathers batch b while batch b+1 traces, so
-    # its LAST gather is exposed: its launches shrink towards the end (128, 64, 32, 16, 8, 8 for 256 steps on 8 GPUs).
+    # At least two launches per timed region so that consecutive launches overlap; up to 32 frames of work per launch
+    # (256 frames = pt_set_batch's maximum).
+    fixed_batch = bool(os.environ.get("PT_BENCH_BATCH"))
     batch = int(os.environ.get("PT_BENCH_BATCH", "0")) or (args.steps + 1) // 2
     batch = max(1, min(32 * world, 256, batch))
+    launch_log = []                  # (tag, frames) of every un-instrumented megakernel launch, in submission order
 
-    def schedule(n_steps):
-        """[(first step, frames)] of the launches that cover n_steps."""
-        out, done = [], 0
-        while done < n_steps:
-            left = n_steps - done
-            b = min(batch, left)
-            if world > 1 and not os.environ.get("PT_BENCH_BATCH"):
-                b = min(b, max(8, left // 2), left)
-            out.append((done, b)); done += b
-        return out
     ctx.set_batch(1)
+    host_stage = False
     if sharded:
         stride = max(rt.tile_layout(width, height, r, world)[1] for r in range(world))
         compact = [torch.zeros(batch, stride, dtype=torch.float32, device="cuda") for _ in range(2)]
@@ -206,6 +254,7 @@ def main():
     ctx.set_batch(batch)
 
     pending = [None]
+    last_frame = {}                  # where the last timed frame ended up (whole-frame runs)
 
     def finish(prev):
         if prev is None:
@@ -237,17 +286,19 @@ def main():
         finish(pending[0])               # gather(b-1) has had the whole launch b to complete
         pending[0] = (work, slot, nf)
 
-    def run(n_steps, first_frame, p):    # called with `stream` current: n_steps frames as the launches of schedule()
-        for k, (first, nf) in enumerate(schedule(n_steps)):
+    def run(n_steps, first_frame, p, tag):    # called with `stream` current: n_steps frames as the launches of schedule()
+        for k, (first, nf) in enumerate(schedule(n_steps, batch, world, fixed_batch)):
             for j in range(nf):
                 p.frame = first_frame + first + j
                 if sharded:
                     ctx.set_compact_buffer(compact[k & 1][j].data_ptr(), stride)
                 else:
                     ctx.set_output_buffer(frames_out[(k & 1) * batch + j].data_ptr(), height * width * 4)
+                    last_frame["index"], last_frame["buf"] = p.frame, (k & 1) * batch + j
                 ctx.render(p)                # the library launches a full batch with its last frame ...
             if nf < batch:
                 ctx.flush()                  # ... and a shorter one here (the slots stay sized for `batch` frames)
+            launch_log.append((tag, nf))
             if sharded:
                 ship(k & 1, nf)
         if sharded:
@@ -256,77 +307,148 @@ def main():
 
     p = params()
     with torch.cuda.stream(stream):
-        run(args.warmup, args.steps, p)
+        run(args.warmup, args.steps, p, "warmup")
     if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     ctx.timing_begin(args.steps)
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
-        run(args.steps, 0, p)
+        run(args.steps, 0, p, "timed")
     torch.cuda.synchronize()
     if sharded:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ctx.timing_collect(args.steps)
+    k_start, k_ms = ctx.timing_collect_spans(args.steps)
 
     if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the last timed frame against the CPU oracle (fixed pixel grid, every sample, bit for bit) -----------------------------
     verified = None
-    if args.verify and rank == 0:
+    bvh4 = None
+    if rank == 0:
+        orc_mod, orc = load_oracle()
+        bvh4 = ctx.read_bvh4()
         with torch.cuda.stream(stream):
-            got = ctx.read_radiance(width, height).copy()           # last de-interleaved (or whole) frame
-            ctx.render(ctx.make_params(width, height, mode=rt.PT_MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED, frame=args.steps - 1))
-            want = ctx.read_radiance(width, height)
-        verified = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+            if sharded:
+                got = ctx.read_radiance(width, height).copy()           # the last de-interleaved frame
+            else:
+                ctx.synchronize()
+                got = frames_out[last_frame["buf"]].reshape(height, width, 4).cpu().numpy()
+        want, _, _ = orc.render(orc.make_params(width, height, NUM_TRIS, mode=orc_mod.MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED,
+                                                frame=args.steps - 1, step=(VERIFY_STEP, VERIFY_STEP)), tris, bvh4)
+        a, b = got[::VERIFY_STEP, ::VERIFY_STEP], want[::VERIFY_STEP, ::VERIFY_STEP]
+        verified = bool(np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32)))
         if not verified:
-            raise SystemExit("bench.py --verify: gathered frame differs from the whole-frame render")
+            print("bench.py: timed frame %d differs from the CPU oracle on the %d-pixel grid (%d of %d pixels)"
+                  % (args.steps - 1, VERIFY_STEP, int((a != b).any(axis=2).sum()), a.shape[0] * a.shape[1]), file=sys.stderr, flush=True)
+    if sharded:
+        ok = torch.tensor([1 if (verified or rank != 0) else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.broadcast(ok, src=0)
+        if int(ok.item()) == 0:
+            ctx.close(); dist.destroy_process_group()
+            sys.exit(3)
+    elif not verified:
+        ctx.close()
+        sys.exit(3)
+
+    # ---- the reference's own call shape: one render() per frame, no batching (src/main.js:70-74) ------------------------------
+    ref_shape = None
+    if world == 1 and not args.no_reference_shape:
+        ctx.set_output_buffer(0, 0)
+        ctx.set_batch(1)
+        n_ref = max(4, min(args.steps, 32))
+        pr = params(whole=True)
+        with torch.cuda.stream(stream):
+            for i in range(4):
+                pr.frame = 5000 + i; ctx.render(pr)
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            for i in range(n_ref):               # frames follow each other like requestAnimationFrame callbacks that do not wait
+                pr.frame = 6000 + i; ctx.render(pr); launch_log.append(("reference-shape pipelined", 1))
+            ctx.synchronize()
+            pipelined = (time.perf_counter() - t1) / n_ref
+            t1 = time.perf_counter()
+            for i in range(n_ref):               # `await render()` + read-back before the next frame
+                pr.frame = 7000 + i; ctx.render(pr); ctx.synchronize(); launch_log.append(("reference-shape solo", 1))
+            solo = (time.perf_counter() - t1) / n_ref
+        ref_shape = {"frames": n_ref, "ms_per_frame_pipelined": round(pipelined * 1e3, 4), "msamples_pipelined": round(width * height * SPP / pipelined / 1e6, 1),
+                     "ms_per_frame_solo": round(solo * 1e3, 4), "msamples_solo": round(width * height * SPP / solo / 1e6, 1),
+                     "note": "pt_set_batch(1): one pt_render per frame as PathTracer.render() is called (src/main.js:70-74); pipelined = no host wait between frames, "
+                             "solo = pt_synchronize after every frame; `value` above uses pt_set_batch, an extension the reference API does not have"}
 
     if rank == 0:
+        log_path = os.environ.get("PT_BENCH_LAUNCH_LOG")
+        if log_path:
+            json.dump({"launches": launch_log, "steps": args.steps, "warmup": args.warmup, "batch": batch, "source_tag": source_tag()}, open(log_path, "w"))
         samples_per_step = width * height * SPP
         value = samples_per_step * args.steps / elapsed / 1e6
-        # one event pair per launch; a launch traces up to `batch` frames
-        n_launch = max(len(kernel_ms), 1)
-        k_avg_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
+        n_launch = max(len(k_ms), 1)
         frames_per_launch = args.steps / n_launch
-        achieved = my_bytes * frames_per_launch / (k_avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # written from a rocprofv3 --pmc pass
-        if os.path.exists(pmc):
+        busy = busy_ms(k_start, k_ms) if len(k_ms) else float("nan")            # ms the GPU spent in trace_paths_kernel (overlaps counted once)
+        busy_per_frame = busy / args.steps
+        algorithmic_gbs = my_bytes / (busy_per_frame * 1e-3) / 1e9
+        # per-frame counter totals of the timed launches of this very command, from the committed rocprofv3 --pmc passes
+        pmc, pmc_info = None, {"file": os.path.relpath(PMC_FILE, ROOT), "present": os.path.exists(PMC_FILE)}
+        if os.path.exists(PMC_FILE) and world == 1 and (width, height) == (WIDTH, HEIGHT):
             try:
-                per_frame = json.load(open(pmc)).get("bytes_per_launch_n%d" % world)     # measured per frame of work
-                traffic = int(per_frame * (args.steps / max(len(kernel_ms), 1))) if per_frame else None
-            except Exception:
-                traffic = None
+                pmc = json.load(open(PMC_FILE))
+                pmc_info.update({"source_tag": pmc.get("source_tag"), "stale": pmc.get("source_tag") != source_tag(),
+                                 "command": pmc.get("command"), "frames_per_launch": pmc.get("frames_per_launch")})
+            except Exception as e:       # a broken summary must not take the throughput line with it
+                pmc, pmc_info["error"] = None, str(e)
+        fractions, traffic, lane_util = {}, None, None
+        if pmc:
+            c = pmc["per_frame"]
+            s = busy_per_frame * 1e-3
+            fractions["valu_issue"] = c["SQ_INSTS_VALU"] / s / 1e9 / VALU_PEAK_GINST
+            fractions["l2_bandwidth"] = (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE / s / 1e9 / L2_PEAK_GBS
+            fractions["hbm_fabric"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / s / 1e9 / HBM_PEAK_GBS
+            lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+            traffic = int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 * frames_per_launch)
+            bound = max(fractions, key=fractions.get)
+            roof = {"valu_issue": ("valu", c["SQ_INSTS_VALU"] / s / 1e9, VALU_PEAK_GINST, "Ginst/s"),
+                    "l2_bandwidth": ("l2", (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE / s / 1e9, L2_PEAK_GBS, "GB/s"),
+                    "hbm_fabric": ("hbm", (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / s / 1e9, HBM_PEAK_GBS, "GB/s")}[bound]
+        else:
+            roof = ("unmeasured", None, None, None)
+        roofline = {
+            "bound": roof[0], "achieved": None if roof[1] is None else round(roof[1], 2), "peak": roof[2], "unit": roof[3],
+            "frac": None if roof[1] is None else round(roof[1] / roof[2], 5), "traffic": traffic,
+            "kernel": "trace_paths_kernel<false,false> (persistent megakernel)",
+            "kernel_busy_ms": round(busy, 4), "kernel_busy_ms_per_frame": round(busy_per_frame, 5), "launches": int(len(k_ms)),
+            "kernel_avg_launch_ms": round(float(np.mean(k_ms)), 4) if len(k_ms) else None, "frames_per_launch": frames_per_launch,
+            "fractions": {k: round(v, 5) for k, v in fractions.items()}, "lane_utilisation": None if lane_util is None else round(lane_util, 4),
+            "pmc": pmc_info,
+            "definition": "frac = (per-frame counter total of the timed launches, rocprofv3 --pmc of this command, profiles/) / (kernel busy time per frame, hipEvents of this run) / peak; "
+                          "valu_issue: SQ_INSTS_VALU x 2 cycles over 1024 SIMDs x 2.4 GHz; l2_bandwidth: (TCC_HIT+TCC_MISS) x 128 B over 34.5 TB/s; "
+                          "hbm_fabric: (FETCH_SIZE+WRITE_SIZE) x 1024 over 8 TB/s (FETCH_SIZE includes Infinity-Cache hits); bound = the largest",
+            "algorithmic": {"GBps": round(algorithmic_gbs, 2), "bytes_per_frame": int(my_bytes), "bytes_per_frame_min_max": [int(min(frame_bytes)), int(max(frame_bytes))],
+                            "over_hbm_peak": round(algorithmic_gbs / HBM_PEAK_GBS, 4),
+                            "note": "SURVEY 8d: 32 B x node records examined + 36 B x triangles tested + 16 B x samples, over the kernel busy time; the working set (67 MB) is "
+                                    "L2 / Infinity-Cache resident, so this rate is served on-die and is NOT a fraction of the HBM roof (it can exceed 1); north_star's '>= 40 % "
+                                    "of HBM roofline' is not met by measured HBM-side traffic (hbm_fabric above) and cannot be for a cache-resident scene",
+                            "counters_all_timed_frames": {k: my_stats[k] for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples")}},
+        }
         out = {
             "metric": "Msamples/sec @1920x1080 Stanford-Dragon-class, 4 spp, 8 bounces",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "verified": verified,
+            "verified_how": "timed frame %d, every %dth pixel in x and y (all %d samples each), bit for bit against oracle/pt_oracle.cpp" % (args.steps - 1, VERIFY_STEP, SPP),
             "config": {"workload": "C2: dragon-class procedural closed mesh (%d tris, seed %d; dragon.glb absent), native LBVH2->BVH4, %dx%d, %d spp, %d bounces, camera (0,0,2.5) identity quat FOV 70, a new frame index (sample set) every step"
                                    % (NUM_TRIS, SCENE_SEED, width, height, SPP, BOUNCES),
                        "triangles": NUM_TRIS, "bvh4_nodes": ctx.scene_info()["numNodes4"], "width": width, "height": height,
-                       "spp": SPP, "max_bounces": BOUNCES, "seed": SEED,
+                       "spp": SPP, "max_bounces": BOUNCES, "seed": SEED, "frames_per_launch": batch,
                        "sharding": ("interleaved 8x8 tiles over %d GPUs, RCCL gather to rank 0" % world) if sharded else "single GPU, whole frame"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "trace_paths_kernel (persistent megakernel)", "kernel_avg_ms": round(k_avg_ms, 4),
-                         "frames_per_launch": frames_per_launch,
-                         "note": "algorithmic bytes (reference record sizes x records examined) over the per-launch duration by hipEvents on the launch stream; "
-                                 "a launch traces up to %d frames and consecutive launches overlap on side streams; the scene is cache resident, so the algorithmic rate "
-                                 "may exceed the HBM peak -- see traffic" % batch,
-                         "achieved_from_throughput": round(my_bytes * args.steps / elapsed / 1e9, 2),
-                         "algorithmic_bytes_per_frame": int(my_bytes), "algorithmic_bytes_per_frame_min_max": [int(min(frame_bytes)), int(max(frame_bytes))],
-                         "algorithmic_bytes_per_launch": int(my_bytes * frames_per_launch),
-                         "counters_all_timed_frames": {k: my_stats[k] for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples")}},
+            "roofline": roofline,
+            "reference_call_shape": ref_shape,
         }
         if world == 1 and not args.no_cpu_baseline and (width, height) == (WIDTH, HEIGHT):
-            bvh4 = ctx.read_bvh4()
-            base, ost = cpu_baseline(tris, bvh4)
-            out["cpu_baseline"] = base
+            out["cpu_baseline"] = cpu_baseline(tris, bvh4)
             out["cpu_baseline_threads"] = cpu_baseline_threads(tris, bvh4)
             out["cpu_baseline_node"] = cpu_baseline_node(tris, bvh4)
         else:

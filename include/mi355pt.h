@@ -174,6 +174,9 @@ int pt_last_render_ms(PtContext* ctx, float* ms);
  * elapsed milliseconds of the recorded launches (oldest first) and their count. */
 int pt_timing_begin(PtContext* ctx, uint32_t capacity);
 int pt_timing_collect(PtContext* ctx, float* ms, uint32_t capacity, uint32_t* count);
+/* The same, plus when each recorded launch started relative to the first one (launches of consecutive batches overlap on the
+ * context's side streams: the union of the [start, start + duration] intervals is the time the GPU was busy tracing). */
+int pt_timing_collect_spans(PtContext* ctx, float* start_ms, float* dur_ms, uint32_t capacity, uint32_t* count);
 int pt_get_stats(PtContext* ctx, PtStats* out);
 /* Full-frame f32 RGBA W*H*4 (tile_count <= 1).  Synchronises. */
 int pt_read_radiance(PtContext* ctx, float* dst, uint64_t dst_floats);

@@ -60,7 +60,7 @@ EXPORTS = [
     "pt_compute_bvh2_sizing", "pt_compute_bvh4_sizing", "pt_morton_sort", "pt_collapse_lbvh2_to_bvh4",
     "pt_bvh2_to_bvh4_wide", "pt_file_write_u32", "pt_file_read_u32", "pt_scene_procedural",
     "pt_set_triangles", "pt_build_bvh", "pt_build_lbvh2", "pt_read_bvh2", "pt_set_bvh4", "pt_set_bvh2",
-    "pt_read_bvh4", "pt_set_spheres", "pt_scene_info", "pt_render", "pt_last_render_ms", "pt_set_batch", "pt_flush", "pt_timing_begin", "pt_timing_collect", "pt_set_compact_buffer", "pt_set_output_buffer", "pt_get_stats", "pt_read_radiance",
+    "pt_read_bvh4", "pt_set_spheres", "pt_scene_info", "pt_render", "pt_last_render_ms", "pt_set_batch", "pt_flush", "pt_timing_begin", "pt_timing_collect", "pt_timing_collect_spans", "pt_set_compact_buffer", "pt_set_output_buffer", "pt_get_stats", "pt_read_radiance",
     "pt_read_rgba8", "pt_read_tonemapped", "pt_tile_layout", "pt_compact_radiance", "pt_deinterleave",
 ]
 
@@ -278,6 +278,12 @@ class Context:
     def debug_set_tune(self, name, value=None):
         """Diagnostics: override one launch heuristic of the megakernel on this context (None restores the default)."""
         self._ck(lib.pt_debug_set_tune(self.h, name.encode(), C.c_uint32(0xFFFFFFFF if value is None else value)))
+
+    def timing_collect_spans(self, capacity):
+        """(start_ms, dur_ms) of the launches recorded since timing_begin; starts are relative to the first launch."""
+        st = np.zeros(capacity, np.float32); ms = np.zeros(capacity, np.float32); n = C.c_uint32()
+        self._ck(lib.pt_timing_collect_spans(self.h, _p(st, C.c_float), _p(ms, C.c_float), C.c_uint32(capacity), C.byref(n)))
+        return st[: n.value].copy(), ms[: n.value].copy()
 
     def set_compact_buffer(self, device_ptr, floats):
         self._ck(lib.pt_set_compact_buffer(self.h, C.c_void_p(device_ptr), C.c_uint64(floats)))

@@ -789,18 +789,24 @@ int pt_timing_begin(PtContext* ctx, uint32_t capacity) {
     return PT_OK;
 }
 
-int pt_timing_collect(PtContext* ctx, float* ms, uint32_t capacity, uint32_t* count) {
+int pt_timing_collect_spans(PtContext* ctx, float* start_ms, float* dur_ms, uint32_t capacity, uint32_t* count) {
     if (int rc = bind(ctx)) return rc;
     if (int rc = flush_pending(ctx)) return rc;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t n = ctx->ring_used / 2;
     uint32_t got = 0;
-    for (uint32_t i = 0; i < n && i < capacity; ++i, ++got)
-        PT_HIP(ctx, hipEventElapsedTime(&ms[i], ctx->ring[2 * i], ctx->ring[2 * i + 1]));
+    for (uint32_t i = 0; i < n && i < capacity; ++i, ++got) {
+        if (dur_ms) PT_HIP(ctx, hipEventElapsedTime(&dur_ms[i], ctx->ring[2 * i], ctx->ring[2 * i + 1]));
+        if (start_ms) { start_ms[i] = 0.0f; if (i) PT_HIP(ctx, hipEventElapsedTime(&start_ms[i], ctx->ring[0], ctx->ring[2 * i])); }
+    }
     if (count) *count = got;
     for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
     ctx->ring.clear(); ctx->ring_used = 0;
     return PT_OK;
+}
+
+int pt_timing_collect(PtContext* ctx, float* ms, uint32_t capacity, uint32_t* count) {
+    return pt_timing_collect_spans(ctx, nullptr, ms, capacity, count);
 }
 
 int pt_last_render_ms(PtContext* ctx, float* ms) {

@@ -87,7 +87,7 @@ __device__ __forceinline__ bool traverse(const RenderArgs& A, const Ray& r, floa
                 if (h2) { if (nslot == 2) { if (fslot != 2) PT_PUSH(rf, tf); } else if (fslot != 2) PT_PUSH(n3.z, t2); }
                 if (h1) { if (nslot == 1) { if (fslot != 1) PT_PUSH(rf, tf); } else if (fslot != 1) PT_PUSH(n3.y, t1); }
 #undef PT_PUSH
-                if (STATS) { if ((uint32_t)(sp + 1) > cnt.maxstack) cnt.maxstack = (uint32_t)(sp + 1); }
+                if (STATS) { const uint32_t depth = (uint32_t)sp + (sp < kStackMax ? 1u : 0u); if (depth > cnt.maxstack) cnt.maxstack = depth; }   // entries incl. the nearest child, if its push fitted
                 if (sp < kStackMax) cur = rn;          // the push of the nearest child would have fitted
                 else { need_pop = true; if (STATS) cnt.drops += 1; }
             }

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                         if (p2) push((uint32_t)w2, __uint_as_float((uint32_t)(w2 >> 32)));
                         if (p1) push((uint32_t)w1, __uint_as_float((uint32_t)(w1 >> 32)));
                     }
-                    if (STATS) { if ((uint32_t)(S.sp + 1) > c_maxstack) c_maxstack = (uint32_t)(S.sp + 1); }
+                    if (STATS) { const uint32_t depth = (uint32_t)S.sp + (S.sp < kStackMax ? 1u : 0u); if (depth > c_maxstack) c_maxstack = depth; }   // entries incl. the nearest child, if its push fitted
                     if (S.sp < kStackMax) S.cur = rn;
                     else { need_pop = true; if (STATS) ++c_drops; }
                 }
