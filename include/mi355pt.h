@@ -213,6 +213,44 @@ int pt_set_output_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
 int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride_floats,
                     uint32_t width, uint32_t height, uint32_t tile_count);
 
+/* ---- one image from all GPUs of the node: a group of contexts inside ONE process ------------------------------
+ *
+ * PathTracer.render() yields one image per call (src/main.js:54-76); a group keeps that call shape over N GPUs.  Member r renders
+ * the 8x8 tiles with (tx + ty) % N == r into a compact buffer (pt_render with tile_rank / tile_count), RCCL gathers the compact
+ * buffers on rank 0 over xGMI (ncclCommInitAll + one ncclGather per batch of frames, every sender on its own link to the root), rank 0
+ * de-interleaves them into the row-major frame (pt_deinterleave).  The scene is replicated (each member builds it on its own GPU);
+ * images are bit-identical for every N.  Accumulating frames (PtRenderParams.accumulate) keep their running sums on the members and
+ * are gathered only when an image is asked for.  pt_group_last_error(NULL): last failure without a group. */
+typedef struct PtGroup PtGroup;
+enum {
+    PT_GROUP_TRANSPORT_RCCL = 0,   /* ncclGather over xGMI; one distinct GPU per member */
+    PT_GROUP_TRANSPORT_COPY = 1    /* diagnostics: hipMemcpyPeerAsync instead of the collective; members may share a GPU (what RCCL refuses),
+                                      so the N > 1 logic can be exercised on a one-GPU machine */
+};
+/* device_ordinals = NULL: devices 0 .. num_devices-1; num_devices = 0: every visible device */
+int  pt_group_create(const int* device_ordinals, uint32_t num_devices, uint32_t transport, PtGroup** out);
+void pt_group_destroy(PtGroup* group);
+const char* pt_group_last_error(const PtGroup* group);
+int  pt_group_size(const PtGroup* group, uint32_t* num_members);
+/* The member context of a rank (borrowed: valid until pt_group_destroy), e.g. rank 0 for pt_read_bvh2 / pt_scene_info. */
+int  pt_group_context(PtGroup* group, uint32_t rank, PtContext** ctx);
+/* scene, replicated on every member: pt_set_triangles / pt_build_bvh / pt_set_bvh2 / pt_set_bvh4 */
+int  pt_group_set_triangles(PtGroup* group, const float* tris, uint32_t num_tris);
+int  pt_group_build_bvh(PtGroup* group);
+int  pt_group_set_bvh2(PtGroup* group, const uint32_t* bvh2, uint64_t words);
+int  pt_group_set_bvh4(PtGroup* group, const uint32_t* bvh4, uint64_t words);
+/* pt_set_batch for every member; the gather then moves one batch per collective */
+int  pt_group_set_batch(PtGroup* group, uint32_t frames_per_launch);
+/* One frame over all members (tile_rank / tile_count of `params` are ignored).  Asynchronous. */
+int  pt_group_render(PtGroup* group, const PtRenderParams* params);
+/* Launch, gather and de-interleave what is queued (a partial batch, an accumulating sequence).  Asynchronous. */
+int  pt_group_flush(PtGroup* group);
+int  pt_group_synchronize(PtGroup* group);
+/* pt_read_radiance / pt_read_rgba8 / pt_read_tonemapped of the last gathered frame (rank 0).  Synchronise. */
+int  pt_group_read_radiance(PtGroup* group, float* dst, uint64_t dst_floats);
+int  pt_group_read_rgba8(PtGroup* group, uint8_t* dst, uint64_t dst_bytes);
+int  pt_group_read_tonemapped(PtGroup* group, int from_rgba8, uint8_t* dst, uint64_t dst_bytes);
+
 #ifdef __cplusplus
 }
 #endif

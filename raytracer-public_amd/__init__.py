@@ -62,6 +62,9 @@ EXPORTS = [
     "pt_set_triangles", "pt_build_bvh", "pt_build_lbvh2", "pt_read_bvh2", "pt_set_bvh4", "pt_set_bvh2",
     "pt_read_bvh4", "pt_set_spheres", "pt_scene_info", "pt_render", "pt_last_render_ms", "pt_set_batch", "pt_flush", "pt_timing_begin", "pt_timing_collect", "pt_timing_collect_spans", "pt_set_compact_buffer", "pt_set_output_buffer", "pt_get_stats", "pt_read_radiance",
     "pt_read_rgba8", "pt_read_tonemapped", "pt_tile_layout", "pt_compact_radiance", "pt_deinterleave",
+    "pt_group_create", "pt_group_destroy", "pt_group_last_error", "pt_group_size", "pt_group_context", "pt_group_set_triangles", "pt_group_build_bvh",
+    "pt_group_set_bvh2", "pt_group_set_bvh4", "pt_group_set_batch", "pt_group_render", "pt_group_flush", "pt_group_synchronize", "pt_group_read_radiance",
+    "pt_group_read_rgba8", "pt_group_read_tonemapped",
 ]
 
 

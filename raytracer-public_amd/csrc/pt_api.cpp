@@ -40,16 +40,16 @@ struct DevBuf {
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto, leaf = kAuto,
-             flush = kAuto, passes = kAuto, slots = kAuto;
+             flush = kAuto, passes = kAuto, slots = kAuto, kernel = kAuto, cull = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"LEAF", &PtTune::leaf}, {"FLUSH", &PtTune::flush}, {"PASSES", &PtTune::passes}, {"SLOTS", &PtTune::slots}};
+            {"FILL", &PtTune::fill}, {"LEAF", &PtTune::leaf}, {"FLUSH", &PtTune::flush}, {"PASSES", &PtTune::passes}, {"SLOTS", &PtTune::slots}, {"KERNEL", &PtTune::kernel}, {"CULL", &PtTune::cull}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "LEAF", "FLUSH", "PASSES", "SLOTS"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "LEAF", "FLUSH", "PASSES", "SLOTS", "KERNEL", "CULL"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -75,9 +75,13 @@ struct PtContext {
     pt::WideBvh wide_meta;           // root info; nodes vector emptied after upload
 
     DevBuf<float> d_tris9;           // reference layout
-    DevBuf<float4> d_trirec;         // 3 x float4 per triangle
+    // One arena for the two record arrays the traversal gathers from: [triangle records, 48 B each, padded to a multiple of
+    // 64 B | wide nodes, 64 B each].  One base address and 32-bit byte offsets address both kinds (pt_megakernel.hip fetches
+    // a record with four quad-cooperative 16-byte loads whose addresses travel between lanes as one register).
+    DevBuf<uint4> d_scene; uint64_t node_off = 0, node_cap = 0; uint32_t scene_tris = 0;
+    float4* trirec() const { return (float4*)d_scene.ptr; }
+    uint4* wide() const { return d_scene.ptr + node_off / 16; }
     DevBuf<uint32_t> d_bvh2, d_bvh4; // reference layouts
-    DevBuf<uint4> d_wide;            // 4 x uint4 per internal node
     DevBuf<uint32_t> d_morton, d_triidx, d_parent, d_flags;
     // device-side scene build (pt_build.hip): scratch kept for rebuilds
     DevBuf<unsigned long long> d_bounds; DevBuf<uint32_t> d_counters, d_code_tmp, d_index_tmp, d_node2, d_subtree, d_ids, d_bnd;
@@ -92,7 +96,10 @@ struct PtContext {
     // dense start of the next; the resolve passes stay in call order on the main stream.
     struct FrameSlot {
         hipStream_t side = nullptr; hipEvent_t resolved = nullptr, done = nullptr; bool used = false;
-        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<float4> cont; DevBuf<uint32_t> flags;
+        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<float4> cont; DevBuf<uint32_t> flags; DevBuf<uint4> path_state;
+        // owned-tile slots that the launch in this slot traces (the others are culled: every camera ray misses the root box)
+        DevBuf<uint32_t> trace_slots; uint32_t* h_trace = nullptr; size_t h_trace_cap = 0; hipEvent_t trace_copied = nullptr;
+        uint32_t cull_key[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t num_trace_tiles = 0; bool cull_valid = false;
         DevBuf<ptk::FrameParams> frame_params; DevBuf<float4*> frame_outs;      // per-frame parameters / targets of the launch in this slot
         const void* primed_ptr = nullptr; size_t primed_samples = 0;   // what the resident prefill covers
     };
@@ -112,6 +119,7 @@ struct PtContext {
     float4* ext_out = nullptr; uint64_t ext_out_floats = 0;      // caller-owned whole-frame target (pt_set_output_buffer)
     const float4* last_full = nullptr;                          // where the last whole-frame result lives (d_out or a caller's buffer)
     bool last_stats = false;
+    uint64_t stats_culled = 0;          // pixel-samples of the last instrumented launch that were culled (counted as one root-box miss each)
     std::vector<hipEvent_t> ring;    // start/stop pairs recorded by pt_render while timing is on
     uint32_t ring_used = 0;
 };
@@ -133,20 +141,71 @@ int bind(PtContext* ctx) {
     return PT_OK;
 }
 
+// Room for `num_tris` triangle records and `nodes` wide nodes; triangle records that are already there survive a regrowth.
+int ensure_scene(PtContext* ctx, uint32_t num_tris, uint64_t nodes) {
+    const uint64_t tri_bytes = ((uint64_t(num_tris) * 48u + 64u + 63u) / 64u) * 64u;      // + 64 B: the 64-byte fetch of the last record over-reads
+    const uint64_t need = tri_bytes + (nodes + 1u) * 64u;
+    if (need >= 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "scene too large: triangle records and BVH nodes are addressed by 32-bit byte offsets (4 GiB)");
+    if (ctx->d_scene.ptr && ctx->node_off == tri_bytes && ctx->node_cap >= nodes) { ctx->scene_tris = num_tris; return PT_OK; }
+    const uint64_t cap_nodes = nodes + nodes / 8u + 16u;
+    uint4* fresh = nullptr;
+    PT_HIP(ctx, hipMalloc((void**)&fresh, tri_bytes + (cap_nodes + 1u) * 64u));
+    if (ctx->d_scene.ptr && ctx->scene_tris == num_tris && num_tris)          // the records of the current triangles move along
+        PT_HIP(ctx, hipMemcpy(fresh, ctx->d_scene.ptr, uint64_t(num_tris) * 48u, hipMemcpyDeviceToDevice));
+    if (ctx->d_scene.ptr) (void)hipFree(ctx->d_scene.ptr);
+    ctx->d_scene.ptr = fresh; ctx->d_scene.cap = size_t((tri_bytes + (cap_nodes + 1u) * 64u) / 16u);
+    ctx->node_off = tri_bytes; ctx->node_cap = cap_nodes; ctx->scene_tris = num_tris;
+    return PT_OK;
+}
+
 int upload_wide(PtContext* ctx, const uint32_t* bvh4, uint64_t words) {
     pt::WideBvh w; std::string err;
     if (!pt::build_wide_bvh(bvh4, words, w, err)) return fail(ctx, PT_ERR_BAD_BVH, err);
     PT_HIP(ctx, ctx->d_bvh4.ensure(words));
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh4.ptr, bvh4, words * 4, hipMemcpyHostToDevice, ctx->stream));
-    PT_HIP(ctx, ctx->d_wide.ensure(w.nodes.size() * 4 + 4));
+    if (int rc = ensure_scene(ctx, ctx->have_tris ? ctx->num_tris : 0u, w.nodes.size())) return rc;
     if (!w.nodes.empty())
-        PT_HIP(ctx, hipMemcpyAsync(ctx->d_wide.ptr, w.nodes.data(), w.nodes.size() * sizeof(pt::WideNode), hipMemcpyHostToDevice, ctx->stream));
+        PT_HIP(ctx, hipMemcpyAsync(ctx->wide(), w.nodes.data(), w.nodes.size() * sizeof(pt::WideNode), hipMemcpyHostToDevice, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die at return
     ctx->num_nodes4 = w.num_nodes4;
     w.nodes.clear(); w.nodes.shrink_to_fit();
     ctx->wide_meta = w;
     ctx->have_bvh = true;
     return PT_OK;
+}
+
+// Tiles whose every camera ray provably misses the root box need no tracing: their samples keep the primed miss value.  The
+// rectangle is the bounding box of the eight projected corners of the root's (f16, exactly representable) bounds, in tile
+// units, widened by a margin of two pixels -- orders of magnitude more than the rounding of the ray set-up (renderer.wgsl:387-395)
+// can move a ray.  No culling when a corner is beside or behind the eye, or when the quaternion is not of unit length (the
+// reference's rotateVectorByQuat is a rotation only then).  Returns false for "trace everything".
+struct TileRect { uint32_t tx0, ty0, tx1, ty1; };     // half-open, in tiles
+bool root_box_rect(const pt::WideBvh& w, const ptk::FrameParams& f, uint32_t width, uint32_t height, TileRect& out) {
+    const double qx = f.quat[0], qy = f.quat[1], qz = f.quat[2], qw = f.quat[3];
+    const double qn = qx * qx + qy * qy + qz * qz + qw * qw;
+    if (!(qn > 0.999 && qn < 1.001) || !(f.focal > 1e-3f) || !(f.aspect > 1e-3f)) return false;
+    const double mn[3] = {pt::half_to_float(w.root_box[0] & 0xffffu), pt::half_to_float(w.root_box[0] >> 16), pt::half_to_float(w.root_box[1] & 0xffffu)};
+    const double mx[3] = {pt::half_to_float(w.root_box[1] >> 16), pt::half_to_float(w.root_box[2] & 0xffffu), pt::half_to_float(w.root_box[2] >> 16)};
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    for (int c = 0; c < 8; ++c) {
+        const double p[3] = {((c & 1) ? mx[0] : mn[0]) - f.cam[0], ((c & 2) ? mx[1] : mn[1]) - f.cam[1], ((c & 4) ? mx[2] : mn[2]) - f.cam[2]};
+        if (!(p[0] == p[0] && p[1] == p[1] && p[2] == p[2])) return false;
+        // v = conj(q) * p * q: the inverse of the camera-to-world rotation
+        const double ux = -qx, uy = -qy, uz = -qz;
+        const double cx = uy * p[2] - uz * p[1], cy = uz * p[0] - ux * p[2], cz = ux * p[1] - uy * p[0];
+        const double dx = uy * cz - uz * cy, dy = uz * cx - ux * cz, dz = ux * cy - uy * cx;
+        const double vx = p[0] + 2.0 * (qw * cx + dx), vy = p[1] + 2.0 * (qw * cy + dy), vz = p[2] + 2.0 * (qw * cz + dz);
+        if (!(vz < -1e-4)) return false;                                 // beside / behind the eye (the camera looks down -z)
+        const double sx = vx / -vz * f.focal / f.aspect, sy = vy / -vz * f.focal;          // p.x, p.y of renderer.wgsl:388
+        const double fx = (sx + 1.0) * 0.5 * width, fy = (sy + 1.0) * 0.5 * height;
+        x0 = fx < x0 ? fx : x0; x1 = fx > x1 ? fx : x1; y0 = fy < y0 ? fy : y0; y1 = fy > y1 ? fy : y1;
+    }
+    const double margin = 2.0;
+    const uint32_t tiles_x = (width + pt::kTile - 1) / pt::kTile, tiles_y = (height + pt::kTile - 1) / pt::kTile;
+    auto lo = [&](double v, uint32_t n) { v = (v - margin) / pt::kTile; return v <= 0.0 ? 0u : (v >= n ? n : uint32_t(v)); };
+    auto hi = [&](double v, uint32_t n) { v = (v + margin) / pt::kTile + 1.0; return v <= 0.0 ? 0u : (v >= n ? n : uint32_t(v)); };
+    out.tx0 = lo(x0, tiles_x); out.tx1 = hi(x1, tiles_x); out.ty0 = lo(y0, tiles_y); out.ty1 = hi(y1, tiles_y);
+    return true;
 }
 
 // Launch the queued frames as one persistent launch (trace on a side stream, resolve on the main stream).
@@ -157,7 +216,9 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     ctx->pending = 0;
     const bool ring = ctx->ring_used + 2 <= ctx->ring.size();
     hipEvent_t e0 = ring ? ctx->ring[ctx->ring_used] : ctx->ev_start, e1 = ring ? ctx->ring[ctx->ring_used + 1] : ctx->ev_stop;
-    uint32_t grid = ptk::megakernel_grid(ctx->num_cus > 0 ? ctx->num_cus : 256);
+    const bool gen2 = PtTune::pick(ctx->tune.kernel, 1u) >= 2u;        // pt_trace2.hip (two ray slots per lane); 1 = trace_paths_kernel
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    uint32_t grid = gen2 ? ptk::trace2_grid(cus) : ptk::megakernel_grid(cus);
     // a tile-sharded frame is a fraction of the work: fewer, denser wavefronts (measured: 1/8 frame best at grid/4);
     // a batch of nf such frames is nf times the work again
     {
@@ -165,14 +226,51 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         if (nf > 1u) div = div > nf ? div / nf : 1u;
         if (div > 1u) grid = (grid + div - 1u) / div;
     }
-    const uint32_t grid_lanes = grid * ptk::megakernel_block();
+    const uint32_t grid_lanes = grid * (gen2 ? 64u : ptk::megakernel_block());
     A.num_frames = nf;
     if (uint64_t(A.num_tiles) * A.spp * nf * 64ull > 0xFFFFFFFFull) {     // item and sample indices are 32-bit
         ctx->pending = 0;
         return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: more than 2^32 pixel-samples in one launch (lower spp, the resolution or the batch)");
     }
     A.batches_per_frame = A.num_tiles * A.spp;
-    A.num_batches = A.batches_per_frame * nf;
+    A.num_sample_batches = A.batches_per_frame * nf;
+    // ---- which owned tiles are traced at all: the union over the launch's frames of the root box's screen rectangle
+    std::vector<uint32_t> traced;                 // owned-tile slots inside the rectangle (empty + cull == false: all of them)
+    bool cull = false; TileRect rect = {0, 0, 0, 0};
+    if (ctx->have_bvh && ctx->wide_meta.root_ref != pt::kInvalid && !ctx->wide_meta.root_degenerate && A.num_tris != 0u && ctx->tune.cull != 0u) {
+        cull = true;
+        for (uint32_t i = 0; i < nf && cull; ++i) {
+            TileRect r;
+            if (!root_box_rect(ctx->wide_meta, ctx->pending_frames[i], A.width, A.height, r)) { cull = false; break; }
+            if (i == 0) rect = r;
+            else { rect.tx0 = std::min(rect.tx0, r.tx0); rect.ty0 = std::min(rect.ty0, r.ty0); rect.tx1 = std::max(rect.tx1, r.tx1); rect.ty1 = std::max(rect.ty1, r.ty1); }
+        }
+        const uint32_t tiles_y = (A.height + pt::kTile - 1) / pt::kTile;
+        if (cull && rect.tx0 == 0u && rect.ty0 == 0u && rect.tx1 >= A.tiles_x && rect.ty1 >= tiles_y) cull = false;     // nothing to leave out
+    }
+    A.num_trace_tiles = A.num_tiles;
+    if (cull) {
+        auto inside = [&](uint32_t tile) { const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x; return tx >= rect.tx0 && tx < rect.tx1 && ty >= rect.ty0 && ty < rect.ty1; };
+        if (sharded) { for (uint32_t sl = 0; sl < A.num_tiles; ++sl) if (inside(ctx->tiles_host[sl])) traced.push_back(sl); }
+        else { for (uint32_t ty = rect.ty0; ty < rect.ty1; ++ty) for (uint32_t tx = rect.tx0; tx < rect.tx1; ++tx) traced.push_back(ty * A.tiles_x + tx); }
+        A.num_trace_tiles = uint32_t(traced.size());
+    }
+    ctx->stats_culled = 0;
+    if (stats && cull) {                          // the oracle traces these rays too: one closest ray, one root record, one sample each
+        uint64_t px_all = 0, px_traced = 0;
+        auto tile_px = [&](uint32_t tile) { const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x; return uint64_t(std::min(8u, A.width - tx * 8u)) * std::min(8u, A.height - ty * 8u); };
+        for (uint32_t sl = 0; sl < A.num_tiles; ++sl) px_all += tile_px(sharded ? ctx->tiles_host[sl] : sl);
+        for (uint32_t sl : traced) px_traced += tile_px(sharded ? ctx->tiles_host[sl] : sl);
+        ctx->stats_culled = (px_all - px_traced) * A.spp * nf;
+    }
+    A.trace_bpf = A.num_trace_tiles * A.spp;
+    A.num_batches = A.trace_bpf * nf;
+    auto magic = [](uint32_t d) { return d > 1u ? uint32_t(0x100000000ull / d) : 0xFFFFFFFFu; };      // d == 1: mulhi gives n - 1 (n > 0), corrected in the kernel
+    A.trace_bpf_magic = magic(A.trace_bpf ? A.trace_bpf : 1u); A.spp_magic = magic(A.spp); A.tiles_x_magic = magic(A.tiles_x);
+    if (A.num_batches == 0u) {
+        // every owned tile is culled (or there is none): nothing to trace, the resolve pass delivers the primed miss values
+        A.trace_bpf = 1u; A.trace_bpf_magic = magic(1u);
+    }
     // Rows of the batch transposition (the order in which the queue walks the (frame, tile, sample) batches).  Rows that are a
     // multiple or a divisor of the frame count keep the frames of a launch aligned: all rows are at the same image position at
     // the same time, so the frames share the BVH nodes they pull through L2.  Long launches take one row per frame (few places
@@ -203,7 +301,8 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         const uint32_t work8_q = nf * 8u / (count ? count : 1u);
         A.xcd_span = PtTune::pick(ctx->tune.xcd, work8_q >= 64u ? 1u : 0u) ? ((per + A.chunk_items - 1u) / A.chunk_items) * A.chunk_items : 0u;
     }
-    A.shade_threshold = PtTune::pick(ctx->tune.shade, PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD); A.leaf_threshold = PtTune::pick(ctx->tune.leaf, PT_LEAF_THRESHOLD);
+    A.shade_threshold = PtTune::pick(ctx->tune.shade, gen2 ? PT2_SERVICE_THRESHOLD : PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD);
+    A.leaf_threshold = PtTune::pick(ctx->tune.leaf, gen2 ? PT2_LEAF_THRESHOLD : PT_LEAF_THRESHOLD);
     A.flush_threshold = PtTune::pick(ctx->tune.flush, sharded ? 0u : PT_FLUSH_THRESHOLD);   // sharded frames are too small to profit from a second pass
     A.cont_passes = PtTune::pick(ctx->tune.passes, PT_MAX_CONT_PASSES);
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
@@ -217,10 +316,10 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     ctx->num_slots = want_slots;
     // Every slot is sized for a full batch of the current setting (largest grid) and prefilled as a whole the first time
     // it is needed; from then on the resolve passes keep the buffers primed, whatever prefix a later launch uses.
-    const size_t n_samples = size_t(A.num_batches) * 64u;
+    const size_t n_samples = size_t(A.num_sample_batches) * 64u;
     const size_t cap_samples = std::max(n_samples, size_t(A.batches_per_frame) * 64u * size_t(ctx->batch_size));
     if (cap_samples > 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: batch too large (more than 2^32 samples per launch)");
-    const uint32_t full_lanes = ptk::megakernel_grid(ctx->num_cus > 0 ? ctx->num_cus : 256) * ptk::megakernel_block();
+    const uint32_t full_lanes = gen2 ? ptk::trace2_grid(cus) * 64u : ptk::megakernel_grid(cus) * ptk::megakernel_block();
     A.pool_capacity = full_lanes * 2u;           // donations can repeat; a full pool just stops donating
     for (int si = 0; si < (stats ? 1 : want_slots); ++si) {
         PtContext::FrameSlot& s = ctx->slots[si];
@@ -231,7 +330,8 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         }
         PT_HIP(ctx, s.queue.ensure(16));
         PT_HIP(ctx, s.samples.ensure(cap_samples));
-        PT_HIP(ctx, s.spill.ensure(size_t(full_lanes) * size_t(64 - PT_SHORT_STACK)));
+        PT_HIP(ctx, s.spill.ensure(size_t(full_lanes) * size_t(gen2 ? ptk::trace2_spill_entries() : uint32_t(64 - PT_SHORT_STACK))));
+        if (gen2) PT_HIP(ctx, s.path_state.ensure(size_t(full_lanes / 64u) * 8u * 64u));
         PT_HIP(ctx, s.cont.ensure(A.cont_passes ? size_t(A.pool_capacity) * 4u * 2u : 4u));
         PT_HIP(ctx, s.flags.ensure(A.cont_passes ? size_t(A.pool_capacity) * 2u : 4u));
         PT_HIP(ctx, s.frame_params.ensure(std::max<size_t>(ctx->batch_size, nf))); PT_HIP(ctx, s.frame_outs.ensure(std::max<size_t>(ctx->batch_size, nf)));
@@ -243,7 +343,25 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     }
     PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(want_slots))];
     A.prime = stats ? 1u : 0u;                   // instrumented launches start from a freshly primed prefix
-    A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr;
+    A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr; A.path_state = sl.path_state.ptr;
+    A.trace_slots = nullptr;
+    if (cull) {
+        // the list travels through a pinned staging buffer of the slot; it is rebuilt only when the rectangle (or the tile share) changes
+        const uint32_t key[8] = {rect.tx0, rect.ty0, rect.tx1, rect.ty1, A.width, A.height, ctx->pending_rank | (ctx->pending_count << 16), A.num_trace_tiles};
+        if (!sl.cull_valid || std::memcmp(key, sl.cull_key, sizeof key) != 0) {
+            if (!sl.trace_copied) PT_HIP(ctx, hipEventCreateWithFlags(&sl.trace_copied, hipEventDisableTiming));
+            else PT_HIP(ctx, hipEventSynchronize(sl.trace_copied));                   // the previous copy out of the staging buffer is done
+            if (sl.h_trace_cap < traced.size()) {
+                if (sl.h_trace) (void)hipHostFree(sl.h_trace);
+                sl.h_trace = nullptr; sl.h_trace_cap = 0;
+                PT_HIP(ctx, hipHostMalloc((void**)&sl.h_trace, std::max<size_t>(traced.size(), 1024) * sizeof(uint32_t), hipHostMallocDefault));
+                sl.h_trace_cap = std::max<size_t>(traced.size(), 1024);
+            }
+            PT_HIP(ctx, sl.trace_slots.ensure(std::max<size_t>(traced.size(), 1)));
+            if (!traced.empty()) std::memcpy(sl.h_trace, traced.data(), traced.size() * sizeof(uint32_t));
+            sl.cull_valid = false;
+        }
+    }
     uint32_t stat_waves = 0;
     if (stats) {
         stat_waves = grid_lanes / 64u;
@@ -255,6 +373,15 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     // lets consecutive frames overlap); the resolve on the main stream waits for the trace.
     if (!ring) PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
     if (sl.used) PT_HIP(ctx, hipStreamWaitEvent(sl.side, sl.resolved, 0));
+    if (cull) {
+        if (!sl.cull_valid) {
+            if (!traced.empty()) PT_HIP(ctx, hipMemcpyAsync(sl.trace_slots.ptr, sl.h_trace, traced.size() * sizeof(uint32_t), hipMemcpyHostToDevice, sl.side));
+            PT_HIP(ctx, hipEventRecord(sl.trace_copied, sl.side));
+            const uint32_t key[8] = {rect.tx0, rect.ty0, rect.tx1, rect.ty1, A.width, A.height, ctx->pending_rank | (ctx->pending_count << 16), A.num_trace_tiles};
+            std::memcpy(sl.cull_key, key, sizeof key); sl.cull_valid = true; sl.num_trace_tiles = A.num_trace_tiles;
+        }
+        A.trace_slots = sl.trace_slots.ptr;
+    }
     if (stats) {
         // the counter blocks are zeroed on the stream the instrumented kernel runs on, behind everything that stream still has
         // to wait for; the previous reader (pt_get_stats / pt_debug_*) copied them synchronously
@@ -274,7 +401,8 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         A.frames = sl.frame_params.ptr; A.outs = sl.frame_outs.ptr;
     }
     // timing ring: events tightly around the trace kernels on the stream they run on
-    PT_HIP(ctx, ptk::launch_trace(A, stats, grid, sl.side, ring ? e0 : nullptr, ring ? e1 : nullptr));
+    if (gen2) PT_HIP(ctx, ptk::launch_trace2(A, stats, grid, sl.side, ring ? e0 : nullptr, ring ? e1 : nullptr));
+    else      PT_HIP(ctx, ptk::launch_trace(A, stats, grid, sl.side, ring ? e0 : nullptr, ring ? e1 : nullptr));
     PT_HIP(ctx, hipEventRecord(sl.done, sl.side));
     PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.done, 0));
     PT_HIP(ctx, ptk::launch_resolve(A, ctx->stream));
@@ -336,7 +464,7 @@ void pt_destroy(PtContext* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)flush_pending(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->d_tris9.release(); ctx->d_trirec.release(); ctx->d_bvh2.release(); ctx->d_bvh4.release(); ctx->d_wide.release();
+    ctx->d_tris9.release(); ctx->d_scene.release(); ctx->d_bvh2.release(); ctx->d_bvh4.release();
     ctx->d_spheres.release(); ctx->d_morton.release(); ctx->d_triidx.release(); ctx->d_parent.release(); ctx->d_flags.release();
     ctx->d_out.release(); ctx->d_accum.release(); ctx->d_compact.release(); ctx->d_compact_accum.release();
     ctx->d_tiles.release(); ctx->d_u32tmp.release(); ctx->d_stats.release();
@@ -345,7 +473,9 @@ void pt_destroy(PtContext* ctx) {
     ctx->d_subtree.release(); ctx->d_ids.release(); ctx->d_bnd.release(); ctx->d_child_pos.release(); ctx->d_build_temp.release();
     if (ctx->h_word) (void)hipHostFree(ctx->h_word);
     for (auto& sl : ctx->slots) {
-        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.cont.release(); sl.flags.release(); sl.frame_params.release(); sl.frame_outs.release();
+        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.path_state.release(); sl.trace_slots.release();
+        if (sl.h_trace) (void)hipHostFree(sl.h_trace);
+        if (sl.trace_copied) (void)hipEventDestroy(sl.trace_copied); sl.cont.release(); sl.flags.release(); sl.frame_params.release(); sl.frame_outs.release();
         if (sl.resolved) (void)hipEventDestroy(sl.resolved);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.side) { (void)hipStreamSynchronize(sl.side); (void)hipStreamDestroy(sl.side); }
@@ -453,10 +583,11 @@ int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris) {
     if (num_tris && !tris) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_triangles: null triangles");
     if (num_tris >= 0x7fffffffu) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_triangles: too many triangles for the 31-bit leaf index");
     PT_HIP(ctx, ctx->d_tris9.ensure(size_t(num_tris) * 9));
-    PT_HIP(ctx, ctx->d_trirec.ensure(size_t(num_tris) * 3 + 4));   // +64 B: the megakernel's unified 64 B fetch over-reads the last record
+    ctx->scene_tris = ~0u;                          // new triangles: nothing in the arena is worth keeping
+    if (int rc = ensure_scene(ctx, num_tris, uint64_t(num_tris) + 16u)) return rc;
     if (num_tris) {
         PT_HIP(ctx, hipMemcpyAsync(ctx->d_tris9.ptr, tris, size_t(num_tris) * 36, hipMemcpyHostToDevice, ctx->stream));
-        PT_HIP(ctx, ptk::launch_tri_records(ctx->d_tris9.ptr, num_tris, ctx->d_trirec.ptr, ctx->stream));   // 48 B records, DESIGN.md section 5
+        PT_HIP(ctx, ptk::launch_tri_records(ctx->d_tris9.ptr, num_tris, ctx->trirec(), ctx->stream));   // 48 B records, DESIGN.md section 5
     }
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->num_tris = num_tris;
@@ -582,8 +713,8 @@ int pt_build_bvh(PtContext* ctx) {
     PT_HIP(ctx, hipMemcpyAsync(root, ctx->d_bvh4.ptr + 1, 32, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t internal = tail[0] + tail[1];
-    PT_HIP(ctx, ctx->d_wide.ensure(size_t(internal) * 4 + 4));
-    PT_HIP(ctx, ptk::launch_wide_nodes(B, ctx->d_bvh4.ptr, m, ctx->d_wide.ptr, ctx->stream));
+    if (int rc = ensure_scene(ctx, n, internal)) return rc;
+    PT_HIP(ctx, ptk::launch_wide_nodes(B, ctx->d_bvh4.ptr, m, ctx->wide(), ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     pt::WideBvh meta;
     meta.num_nodes4 = m;
@@ -667,7 +798,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     }
 
     ptk::RenderArgs A; std::memset(&A, 0, sizeof(A));
-    A.nodes = ctx->d_wide.ptr; A.tris = ctx->d_trirec.ptr; A.bvh4_ref = ctx->d_bvh4.ptr; A.tris9 = ctx->d_tris9.ptr;
+    A.nodes = ctx->wide(); A.tris = ctx->trirec(); A.scene = ctx->d_scene.ptr; A.node_off = uint32_t(ctx->node_off); A.bvh4_ref = ctx->d_bvh4.ptr; A.tris9 = ctx->d_tris9.ptr;
     A.width = p->width; A.height = p->height; A.focal = p->focal; A.aspect = p->aspect;
     std::memcpy(A.cam, p->cam_pos, 12); std::memcpy(A.quat, p->cam_quat, 16);
     A.num_tris = p->num_tris; A.frame = p->frame;
@@ -724,6 +855,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     if (stats) {
         if (!mega_path) {      // the megakernel zeroes the block itself, on the stream its trace runs on (flush_pending_stats)
             if (int rc = flush_pending(ctx)) return rc;
+            ctx->stats_culled = 0;
             PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(unsigned long long), ctx->stream));
         }
         A.stats = ctx->d_stats.ptr;
@@ -829,6 +961,10 @@ int pt_get_stats(PtContext* ctx, PtStats* out) {
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out->rays_closest = h[0]; out->rays_shadow = h[1]; out->nodes_examined = h[2]; out->tris_tested = h[3];
     out->stack_drops = h[4]; out->max_stack = h[5]; out->samples = h[6];
+    if (ctx->stats_culled) {                      // culled camera rays: generated, one root record examined, missed (renderer.wgsl:240-262)
+        out->rays_closest += ctx->stats_culled; out->nodes_examined += ctx->stats_culled; out->samples += ctx->stats_culled;
+        if (out->max_stack < 1u) out->max_stack = 1u;
+    }
     return PT_OK;
 }
 

@@ -131,6 +131,34 @@ __device__ __forceinline__ F3 cosine_dir(F3 n, float u1, float u2) {
     return (t * lx + bt * ly) + n * lz;
 }
 
+// n / d and n % d for a divisor whose magic = floor(2^32 / d) comes from the host: estimate by multiply-high (never too large, at
+// most one too small), one correction
+__device__ __forceinline__ void divmod_magic(uint32_t n, uint32_t d, uint32_t magic, uint32_t& q, uint32_t& r) {
+    q = __umulhi(n, magic); r = n - q * d;
+    if (r >= d) { r -= d; ++q; }
+}
+
+// One logical queue item -> the pixel-sample it stands for.  64 consecutive logical items are one (frame, traced tile, sample) batch;
+// consecutive logical batches are perm_cols batches apart in (frame, tile, sample) order (a perm_rows-row transposition, pt_api.cpp).
+struct ItemInfo { uint32_t sample_index, fid, px, py, s; bool valid; };
+__device__ __forceinline__ ItemInfo decode_item(const RenderArgs& A, uint32_t logical) {
+    ItemInfo it;
+    const uint32_t lb = logical >> 6, p = logical & 63u;
+    uint32_t pcol, prow; divmod_magic(lb, A.perm_rows, A.perm_rows_magic, pcol, prow);
+    const uint32_t q = prow * A.perm_cols + pcol;                       // batch in (frame, traced tile, sample) order
+    const bool in_range = q < A.num_batches;
+    uint32_t fid, qq; divmod_magic(in_range ? q : 0u, A.trace_bpf, A.trace_bpf_magic, fid, qq);
+    uint32_t tslot, s; divmod_magic(qq, A.spp, A.spp_magic, tslot, s);
+    const uint32_t slot = A.trace_slots ? A.trace_slots[tslot] : tslot;  // owned-tile slot
+    const uint32_t tile = A.tiles ? A.tiles[slot] : slot;
+    uint32_t ty, tx; divmod_magic(tile, A.tiles_x, A.tiles_x_magic, ty, tx);
+    it.px = tx * 8u + (p & 7u); it.py = ty * 8u + (p >> 3);
+    it.fid = fid; it.s = s;
+    it.sample_index = ((fid * A.batches_per_frame + slot * A.spp + s) << 6) + p;
+    it.valid = in_range & (it.px < A.width) & (it.py < A.height);
+    return it;
+}
+
 constexpr float kEpsOrigin = 1e-4f;
 constexpr float kBgPrimary = 0.01f;    // renderer.wgsl:410
 constexpr float kSkyAmbient = 0.15f;   // renderer.wgsl:352

@@ -46,6 +46,10 @@ constexpr uint32_t kShadowBit = 1u << 16, kContBit = 1u << 17;
 template <bool STATS, bool CONT>
 __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kernel(const RenderArgs A) {
     __shared__ unsigned long long lds_stack[PT_MEGA_BLOCK / 64][kShort][64];
+#if PT_FETCH_DMA
+    static_assert(PT_MEGA_BLOCK == 64, "the landing zone is per wavefront");
+    __shared__ __attribute__((aligned(16))) char lds_land[4 * PT_LAND_STRIDE];
+#endif
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     unsigned long long* const stk = &lds_stack[wave][0][lane];          // entry i at stk[i * 64]: (tmin bits << 32) | ref
     unsigned long long* const spill = (unsigned long long*)A.spill + ((size_t)blockIdx.x * PT_MEGA_BLOCK + threadIdx.x);   // entry j at spill[j * spill_stride]
@@ -239,22 +243,9 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                             if (STATS) ++c_closest;
                             phase = begin_ray() ? kPhaseTrav : kPhaseDone;
                         } else {
-                        // logical item -> batch permutation: 64 consecutive logical items are one (tile, sample) batch; consecutive
-                        // logical batches are perm_cols batches apart in (frame, image) order -- a perm_rows-row transposition
-                        const uint32_t logical = chunk_next + rank;
-                        const uint32_t lb = logical >> 6;
-                        uint32_t pcol = __umulhi(lb, A.perm_rows_magic), prow = lb - pcol * A.perm_rows;       // lb / rows, lb % rows (estimate, then one correction)
-                        if (prow >= A.perm_rows) { prow -= A.perm_rows; ++pcol; }
-                        const uint32_t q = prow * A.perm_cols + pcol;
-                        const bool in_range = q < A.num_batches;
-                        const uint32_t item = q * 64u + (logical & 63u);
-                        const uint32_t p = item & 63u;
-                        const uint32_t fid = in_range ? q / A.batches_per_frame : 0u, qq = q - fid * A.batches_per_frame;
-                        const uint32_t s = qq % A.spp, slot = in_range ? qq / A.spp : 0u;
-                        const uint32_t tile = A.tiles ? A.tiles[slot] : slot;
-                        const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
-                        const uint32_t px = tx * 8u + (p & 7u), py = ty * 8u + (p >> 3);
-                        if (in_range && px < A.width && py < A.height) {
+                        const ItemInfo it = decode_item(A, chunk_next + rank);
+                        if (it.valid) {
+                            const uint32_t fid = it.fid, px = it.px, py = it.py, s = it.s, item = it.sample_index;
                             const FrameParams fp = frames[fid];
                             const uint32_t key = sample_key(fp.seed, py * A.width + px, fp.frame * A.spp + s);
                             const Ray r = primary_ray_fp(A, fp, (float)px + rnd(key, 0, 0), (float)py + rnd(key, 0, 1));
@@ -287,6 +278,39 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
         // lane can make progress on nodes); each lane's own visit sequence is unchanged.
         const unsigned long long m_leaf = __ballot(phase == kPhaseTrav && (S.cur & kLeaf) != 0u);
         const bool do_leaf = (uint32_t)__popcll(m_leaf) >= A.leaf_threshold || m_leaf == m_trav;
+#if PT_FETCH_DMA
+        // Record fetch, all 64 lanes (EXEC is full here).  A lane's record -- the 64 B of an internal node or the 48 B of a triangle,
+        // whichever it stands at -- is fetched by its QUAD: in instruction k the four lanes of a quad load the four 16-byte pieces of
+        // the record wanted by the quad's lane k, straight into LDS (global_load_lds_dwordx4: landing zone k, 16 bytes per lane), and
+        // the owner reads its 64 bytes back.  The texture path then sees 16 coalesced 64-byte accesses per instruction instead of 64
+        // scattered 16-byte ones (tools/probes/gather64.hip: 2.1 times the gather rate; the kernel was bound by exactly that unit,
+        // profiles/README.md).  Lanes that do not step ask for the first record of the arena.
+        const bool stepping = phase == kPhaseTrav && (do_leaf || (S.cur & kLeaf) == 0u);
+        uint4 n0, n1, n2, n3;
+        {
+            const bool leaf_f = (S.cur & kLeaf) != 0u;
+            const uint32_t ti_f = S.cur & 0x7fffffffu;
+            uint32_t my_off = leaf_f ? ((ti_f < A.num_tris) ? ti_f * 48u : 0u) : A.node_off + S.cur * 64u;
+            if (!stepping) my_off = 0u;
+            const uint32_t piece = (lane & 3u) * 16u;
+            const char* const base_ptr = (const char*)A.scene;
+#define PT_DMA_K(K) { const uint32_t o_k = (uint32_t)__builtin_amdgcn_mov_dpp((int)my_off, (K) * 0x55, 0xf, 0xf, true) + piece;   /* quad_perm:[K,K,K,K] */ \
+                      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_ptr + o_k), \
+                                                       (__attribute__((address_space(3))) void*)(lds_land + (K) * PT_LAND_STRIDE), 16, 0, 0); }
+            PT_DMA_K(0) PT_DMA_K(1) PT_DMA_K(2) PT_DMA_K(3)
+#undef PT_DMA_K
+            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): the four pieces of every record have landed
+            asm volatile("" ::: "memory");
+            const uint4* mine = (const uint4*)(lds_land + (lane & 3u) * PT_LAND_STRIDE + (lane >> 2) * 64u);
+            n0 = mine[0]; n1 = mine[1]; n2 = mine[2]; n3 = mine[3];
+        }
+        if (stepping) {
+            bool need_pop = false;
+            Ray r; r.o = S.o; r.d = S.d; r.inv = S.inv;
+            const bool at_leaf = (S.cur & kLeaf) != 0u;
+            const uint32_t ti = S.cur & 0x7fffffffu;
+            const bool tri_ok = ti < A.num_tris;
+#else
         if (phase == kPhaseTrav && (do_leaf || (S.cur & kLeaf) == 0u)) {
             bool need_pop = false;
             Ray r; r.o = S.o; r.d = S.d; r.inv = S.inv;
@@ -302,6 +326,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
             // keep the four loads here: without this the compiler sinks them into the two branches again
             asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z), "+v"(n1.w),
                               "+v"(n2.x), "+v"(n2.y), "+v"(n2.z), "+v"(n2.w), "+v"(n3.x), "+v"(n3.y), "+v"(n3.z), "+v"(n3.w));
+#endif
             if (at_leaf) {
                 if (tri_ok) {
                     const float4 a = make_float4(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z), __uint_as_float(n0.w));
@@ -389,7 +414,8 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                     if (__builtin_expect(S.sp >= kShort, 0)) e = *(volatile unsigned long long*)&spill[(size_t)(S.sp - kShort) * spill_stride];   // volatile: keeps the rare global read out of the LDS fast path
                     if (__uint_as_float((uint32_t)(e >> 32)) < S.best_t) { S.cur = (uint32_t)e; found = true; break; }
                 }
-                if (!found) phase = kPhaseDone;
+                // a camera ray that found nothing leaves its sample at the primed miss value (0 + 1 * 0.01, renderer.wgsl:410): no shade pass, the lane is free
+                if (!found) phase = (S.bounce == 0u && S.best_tri == kInvalidRef) ? kPhaseIdle : kPhaseDone;
             }
         }
         if (STATS) { const unsigned long long dt = __builtin_amdgcn_s_memtime() - cy_mark; cy_step += dt; if (!queue_empty) cy_step_q += dt; }
@@ -485,7 +511,7 @@ hipError_t launch_trace(const RenderArgs& A0, bool stats, uint32_t grid_blocks, 
         // buffer; afterwards resolve_kernel leaves both ready for the slot's next frame
         e = hipMemsetAsync(A.queue, 0, 16 * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
-        const uint32_t n_samples = A.num_batches * 64u;
+        const uint32_t n_samples = A.num_sample_batches * 64u;
         hipLaunchKernelGGL(prefill_samples_kernel, dim3(2048), dim3(256), 0, stream, A.samples, n_samples);
         e = hipGetLastError(); if (e != hipSuccess) return e;
     }
@@ -525,7 +551,7 @@ hipError_t launch_trace(const RenderArgs& A0, bool stats, uint32_t grid_blocks, 
 }
 
 hipError_t launch_resolve(const RenderArgs& A, hipStream_t stream) {
-    if (A.total_items == 0u) return hipSuccess;
+    if (A.num_tiles == 0u || A.num_frames == 0u) return hipSuccess;       // total_items may be 0 (every tile culled): the primed miss values are still delivered
     const uint32_t n = A.num_tiles * 64u;
     if (A.accum) hipLaunchKernelGGL(resolve_kernel<true>, dim3((n + 255u) / 256u, 1), dim3(256), 0, stream, A);
     else         hipLaunchKernelGGL(resolve_kernel<false>, dim3((n + 255u) / 256u, A.num_frames), dim3(256), 0, stream, A);
@@ -556,7 +582,11 @@ hipError_t launch_prime(uint32_t* queue, float4* samples, uint32_t n_samples, hi
     return hipGetLastError();
 }
 
-uint32_t megakernel_grid(int num_cus) { return (uint32_t)num_cus * PT_MEGA_WAVES_PER_SIMD * (256 / PT_MEGA_BLOCK); }
+// grid = residency: what the register budget (waves per SIMD) and the LDS (160 KB per CU) admit
+uint32_t megakernel_grid(int num_cus) {
+    const uint32_t by_regs = PT_MEGA_WAVES_PER_SIMD * (256 / PT_MEGA_BLOCK), by_lds = 163840u / ((PT_MEGA_LDS_BYTES + 255u) / 256u * 256u) / (PT_MEGA_BLOCK / 64);
+    return (uint32_t)num_cus * (by_regs < by_lds ? by_regs : by_lds);
+}
 uint32_t megakernel_block() { return PT_MEGA_BLOCK; }
 
 

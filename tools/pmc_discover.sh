@@ -23,7 +23,8 @@ B = float(os.environ["PB_BATCH"])
 res = collections.OrderedDict()
 for f in sorted(glob.glob("$OUT/pass*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
-        if "trace_paths" not in row.get("Kernel_Name", ""): continue
+        kn = row.get("Kernel_Name", "")
+        if "trace_paths" not in kn and "trace2" not in kn: continue
         res.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 # only full launches (the warm-up runs full batches too); per-frame means
 summary = {k: {"launches": len(v), "mean_per_frame": sum(v) / len(v) / B} for k, v in res.items()}

@@ -37,6 +37,19 @@ __global__ __launch_bounds__(64, WPS) void gather_kernel(const uint4* __restrict
         } else if (V == 3) {
             const uint4* r = table + (size_t)idx * 4;
             a = r[0]; b = r[1]; c = a; d = b;
+        } else if (V == 6) {
+            // like V0, but the record's cache line is brought in by the first 16-byte load alone: the other three issue only after it has
+            // returned, so they are plain L1 hits instead of accesses to a line whose fill is still in flight
+            const uint4* r = table + (size_t)idx * 4;
+            a = r[0];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w) :: "memory");
+            b = r[1]; c = r[2]; d = r[3];
+        } else if (V == 7) {
+            // like V6 with a one-dword touch
+            const uint4* r = table + (size_t)idx * 4;
+            uint32_t touch = ((const uint32_t*)r)[0];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch) :: "memory");
+            a = r[0]; b = r[1]; c = r[2]; d = r[3]; a.x ^= touch & 0u;
         } else if (V == 4) {
             // LDS-DMA, owners inside the quad: in instruction k the four lanes of a quad fetch the four 16-byte pieces of the record
             // wanted by the quad's lane k, straight into LDS (landing zone k, 16 bytes per lane); the owner reads its 64 bytes back
@@ -107,6 +120,10 @@ int main(int argc, char** argv) {
         if (run<3, 0>("V3 2 x dwordx4 per lane (32 B)", table, mask, hot_mask, cold_of_256, out, grid, iters)) return 1;
         if (run<1, 0>("V1 1 x dwordx4 per lane (16 B)", table, mask, hot_mask, cold_of_256, out, grid, iters)) return 1;
         if (run<2, 0>("V2 quad-cooperative + LDS", table, mask, hot_mask, cold_of_256, out, grid, iters)) return 1;
+        if (run<6, 0>("V6 first 16 B, wait, then 48 B", table, mask, hot_mask, cold_of_256, out, grid, iters)) return 1;
+        if (run<7, 0>("V7 touch dword, wait, then 64 B", table, mask, hot_mask, cold_of_256, out, grid, iters)) return 1;
+        if (run<6, 100>("V6 + 100 dependent FMA", table, mask, hot_mask, cold_of_256, out, grid, iters)) return 1;
+        if (run<4, 100>("V4 + 100 dependent FMA", table, mask, hot_mask, cold_of_256, out, grid, iters)) return 1;
         if (run<4, 0>("V4 LDS-DMA quad-cooperative", table, mask, hot_mask, cold_of_256, out, grid, iters)) return 1;
         if (run<4, 250>("V4 + 250 dependent FMA", table, mask, hot_mask, cold_of_256, out, grid, iters)) return 1;
         if (run<0, 250, 8>("V0 + 250 FMA, 8 waves/SIMD", table, mask, hot_mask, cold_of_256, out, grid, iters)) return 1;
