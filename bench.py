@@ -364,7 +364,7 @@ def main():
         pr = params(whole=True)
         with torch.cuda.stream(stream):
             for i in range(4):
-                pr.frame = 5000 + i; ctx.render(pr)
+                pr.frame = 5000 + i; ctx.render(pr); launch_log.append(("reference-shape warmup", 1))
             ctx.synchronize()
             t1 = time.perf_counter()
             for i in range(n_ref):               # frames follow each other like requestAnimationFrame callbacks that do not wait

@@ -23,6 +23,7 @@ PT_MODE_REFERENCE_PACKET, PT_MODE_REFERENCE, PT_MODE_PATH = 0, 1, 2
 PT_FLAG_STATS = 1
 PT_FLAG_SIMPLE_KERNEL = 2
 PT_FLAG_BRUTE_FORCE = 4
+PT_FLAG_COMPACT = 8
 SCENE_DRAGON_CLASS, SCENE_SPONZA_CLASS = 0, 1
 
 
@@ -326,6 +327,97 @@ class Context:
         self._ck(lib.pt_deinterleave(self.h, C.c_void_p(gathered_device_ptr), C.c_uint64(stride_floats),
                                      C.c_uint32(width), C.c_uint32(height), C.c_uint32(tile_count)))
         self._last = (width, height)
+
+
+PT_GROUP_TRANSPORT_RCCL, PT_GROUP_TRANSPORT_COPY = 0, 1
+
+
+class Group:
+    """Several GPUs, one image per render(): the pt_group_* entry points (one context per device inside this process, tile shares
+    gathered on rank 0 over RCCL, de-interleaved there).  `devices=None` takes every visible device."""
+
+    def __init__(self, devices=None, transport=PT_GROUP_TRANSPORT_RCCL):
+        lib.pt_group_last_error.restype = C.c_char_p
+        lib.pt_group_last_error.argtypes = [C.c_void_p]
+        lib.pt_group_destroy.restype = None
+        lib.pt_group_destroy.argtypes = [C.c_void_p]
+        h = C.c_void_p()
+        if devices is None:
+            rc = lib.pt_group_create(None, C.c_uint32(0), C.c_uint32(transport), C.byref(h))
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = lib.pt_group_create(arr, C.c_uint32(len(devices)), C.c_uint32(transport), C.byref(h))
+        if rc != 0:
+            msg = lib.pt_group_last_error(None)
+            raise PtError(rc, msg.decode() if msg else "")
+        self.h = h
+        self.num_tris = 0
+
+    def _ck(self, rc):
+        if rc != 0:
+            msg = lib.pt_group_last_error(self.h)
+            raise PtError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.pt_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        n = C.c_uint32()
+        self._ck(lib.pt_group_size(self.h, C.byref(n)))
+        return n.value
+
+    def set_triangles(self, tris):
+        tris = np.ascontiguousarray(tris, np.float32).reshape(-1)
+        self._ck(lib.pt_group_set_triangles(self.h, _p(tris, C.c_float), C.c_uint32(tris.size // 9)))
+        self.num_tris = tris.size // 9
+
+    def build_bvh(self):
+        self._ck(lib.pt_group_build_bvh(self.h))
+
+    def set_bvh4(self, bvh4):
+        bvh4 = np.ascontiguousarray(bvh4, np.uint32)
+        self._ck(lib.pt_group_set_bvh4(self.h, _p(bvh4, C.c_uint32), C.c_uint64(bvh4.size)))
+
+    def set_bvh2(self, bvh2):
+        bvh2 = np.ascontiguousarray(bvh2, np.uint32)
+        self._ck(lib.pt_group_set_bvh2(self.h, _p(bvh2, C.c_uint32), C.c_uint64(bvh2.size)))
+
+    def set_batch(self, frames_per_launch):
+        self._ck(lib.pt_group_set_batch(self.h, C.c_uint32(frames_per_launch)))
+
+    def make_params(self, *a, **kw):
+        kw.setdefault("num_tris", self.num_tris)
+        return Context.make_params(self, *a, **kw)
+
+    def render(self, params):
+        self._ck(lib.pt_group_render(self.h, C.byref(params)))
+        self._last = (params.width, params.height)
+
+    def flush(self):
+        self._ck(lib.pt_group_flush(self.h))
+
+    def synchronize(self):
+        self._ck(lib.pt_group_synchronize(self.h))
+
+    def read_radiance(self):
+        w, h = self._last
+        out = np.zeros((h, w, 4), np.float32)
+        self._ck(lib.pt_group_read_radiance(self.h, _p(out, C.c_float), C.c_uint64(out.size)))
+        return out
+
+    def read_rgba8(self):
+        w, h = self._last
+        out = np.zeros((h, w, 4), np.uint8)
+        self._ck(lib.pt_group_read_rgba8(self.h, _p(out, C.c_uint8), C.c_uint64(out.size)))
+        return out
 
 
 class PathTracer:

@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,16 +41,16 @@ struct DevBuf {
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto, leaf = kAuto,
-             flush = kAuto, passes = kAuto, slots = kAuto, kernel = kAuto, cull = kAuto;
+             flush = kAuto, passes = kAuto, slots = kAuto, cull = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"LEAF", &PtTune::leaf}, {"FLUSH", &PtTune::flush}, {"PASSES", &PtTune::passes}, {"SLOTS", &PtTune::slots}, {"KERNEL", &PtTune::kernel}, {"CULL", &PtTune::cull}};
+            {"FILL", &PtTune::fill}, {"LEAF", &PtTune::leaf}, {"FLUSH", &PtTune::flush}, {"PASSES", &PtTune::passes}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "LEAF", "FLUSH", "PASSES", "SLOTS", "KERNEL", "CULL"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "LEAF", "FLUSH", "PASSES", "SLOTS", "CULL"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -76,8 +77,7 @@ struct PtContext {
 
     DevBuf<float> d_tris9;           // reference layout
     // One arena for the two record arrays the traversal gathers from: [triangle records, 48 B each, padded to a multiple of
-    // 64 B | wide nodes, 64 B each].  One base address and 32-bit byte offsets address both kinds (pt_megakernel.hip fetches
-    // a record with four quad-cooperative 16-byte loads whose addresses travel between lanes as one register).
+    // 64 B | wide nodes, 64 B each]: one allocation, one base address, 32-bit byte offsets reach both kinds.
     DevBuf<uint4> d_scene; uint64_t node_off = 0, node_cap = 0; uint32_t scene_tris = 0;
     float4* trirec() const { return (float4*)d_scene.ptr; }
     uint4* wide() const { return d_scene.ptr + node_off / 16; }
@@ -96,7 +96,7 @@ struct PtContext {
     // dense start of the next; the resolve passes stay in call order on the main stream.
     struct FrameSlot {
         hipStream_t side = nullptr; hipEvent_t resolved = nullptr, done = nullptr; bool used = false;
-        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<float4> cont; DevBuf<uint32_t> flags; DevBuf<uint4> path_state;
+        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<float4> cont; DevBuf<uint32_t> flags;
         // owned-tile slots that the launch in this slot traces (the others are culled: every camera ray misses the root box)
         DevBuf<uint32_t> trace_slots; uint32_t* h_trace = nullptr; size_t h_trace_cap = 0; hipEvent_t trace_copied = nullptr;
         uint32_t cull_key[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t num_trace_tiles = 0; bool cull_valid = false;
@@ -216,9 +216,8 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     ctx->pending = 0;
     const bool ring = ctx->ring_used + 2 <= ctx->ring.size();
     hipEvent_t e0 = ring ? ctx->ring[ctx->ring_used] : ctx->ev_start, e1 = ring ? ctx->ring[ctx->ring_used + 1] : ctx->ev_stop;
-    const bool gen2 = PtTune::pick(ctx->tune.kernel, 1u) >= 2u;        // pt_trace2.hip (two ray slots per lane); 1 = trace_paths_kernel
     const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    uint32_t grid = gen2 ? ptk::trace2_grid(cus) : ptk::megakernel_grid(cus);
+    uint32_t grid = ptk::megakernel_grid(cus);
     // a tile-sharded frame is a fraction of the work: fewer, denser wavefronts (measured: 1/8 frame best at grid/4);
     // a batch of nf such frames is nf times the work again
     {
@@ -226,7 +225,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         if (nf > 1u) div = div > nf ? div / nf : 1u;
         if (div > 1u) grid = (grid + div - 1u) / div;
     }
-    const uint32_t grid_lanes = grid * (gen2 ? 64u : ptk::megakernel_block());
+    const uint32_t grid_lanes = grid * ptk::megakernel_block();
     A.num_frames = nf;
     if (uint64_t(A.num_tiles) * A.spp * nf * 64ull > 0xFFFFFFFFull) {     // item and sample indices are 32-bit
         ctx->pending = 0;
@@ -301,8 +300,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         const uint32_t work8_q = nf * 8u / (count ? count : 1u);
         A.xcd_span = PtTune::pick(ctx->tune.xcd, work8_q >= 64u ? 1u : 0u) ? ((per + A.chunk_items - 1u) / A.chunk_items) * A.chunk_items : 0u;
     }
-    A.shade_threshold = PtTune::pick(ctx->tune.shade, gen2 ? PT2_SERVICE_THRESHOLD : PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD);
-    A.leaf_threshold = PtTune::pick(ctx->tune.leaf, gen2 ? PT2_LEAF_THRESHOLD : PT_LEAF_THRESHOLD);
+    A.shade_threshold = PtTune::pick(ctx->tune.shade, PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD); A.leaf_threshold = PtTune::pick(ctx->tune.leaf, PT_LEAF_THRESHOLD);
     A.flush_threshold = PtTune::pick(ctx->tune.flush, sharded ? 0u : PT_FLUSH_THRESHOLD);   // sharded frames are too small to profit from a second pass
     A.cont_passes = PtTune::pick(ctx->tune.passes, PT_MAX_CONT_PASSES);
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
@@ -319,7 +317,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     const size_t n_samples = size_t(A.num_sample_batches) * 64u;
     const size_t cap_samples = std::max(n_samples, size_t(A.batches_per_frame) * 64u * size_t(ctx->batch_size));
     if (cap_samples > 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: batch too large (more than 2^32 samples per launch)");
-    const uint32_t full_lanes = gen2 ? ptk::trace2_grid(cus) * 64u : ptk::megakernel_grid(cus) * ptk::megakernel_block();
+    const uint32_t full_lanes = ptk::megakernel_grid(cus) * ptk::megakernel_block();
     A.pool_capacity = full_lanes * 2u;           // donations can repeat; a full pool just stops donating
     for (int si = 0; si < (stats ? 1 : want_slots); ++si) {
         PtContext::FrameSlot& s = ctx->slots[si];
@@ -330,8 +328,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         }
         PT_HIP(ctx, s.queue.ensure(16));
         PT_HIP(ctx, s.samples.ensure(cap_samples));
-        PT_HIP(ctx, s.spill.ensure(size_t(full_lanes) * size_t(gen2 ? ptk::trace2_spill_entries() : uint32_t(64 - PT_SHORT_STACK))));
-        if (gen2) PT_HIP(ctx, s.path_state.ensure(size_t(full_lanes / 64u) * 8u * 64u));
+        PT_HIP(ctx, s.spill.ensure(size_t(full_lanes) * size_t(64 - PT_SHORT_STACK)));
         PT_HIP(ctx, s.cont.ensure(A.cont_passes ? size_t(A.pool_capacity) * 4u * 2u : 4u));
         PT_HIP(ctx, s.flags.ensure(A.cont_passes ? size_t(A.pool_capacity) * 2u : 4u));
         PT_HIP(ctx, s.frame_params.ensure(std::max<size_t>(ctx->batch_size, nf))); PT_HIP(ctx, s.frame_outs.ensure(std::max<size_t>(ctx->batch_size, nf)));
@@ -343,7 +340,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     }
     PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(want_slots))];
     A.prime = stats ? 1u : 0u;                   // instrumented launches start from a freshly primed prefix
-    A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr; A.path_state = sl.path_state.ptr;
+    A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr;
     A.trace_slots = nullptr;
     if (cull) {
         // the list travels through a pinned staging buffer of the slot; it is rebuilt only when the rectangle (or the tile share) changes
@@ -401,8 +398,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         A.frames = sl.frame_params.ptr; A.outs = sl.frame_outs.ptr;
     }
     // timing ring: events tightly around the trace kernels on the stream they run on
-    if (gen2) PT_HIP(ctx, ptk::launch_trace2(A, stats, grid, sl.side, ring ? e0 : nullptr, ring ? e1 : nullptr));
-    else      PT_HIP(ctx, ptk::launch_trace(A, stats, grid, sl.side, ring ? e0 : nullptr, ring ? e1 : nullptr));
+    PT_HIP(ctx, ptk::launch_trace(A, stats, grid, sl.side, ring ? e0 : nullptr, ring ? e1 : nullptr));
     PT_HIP(ctx, hipEventRecord(sl.done, sl.side));
     PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.done, 0));
     PT_HIP(ctx, ptk::launch_resolve(A, ctx->stream));
@@ -473,7 +469,7 @@ void pt_destroy(PtContext* ctx) {
     ctx->d_subtree.release(); ctx->d_ids.release(); ctx->d_bnd.release(); ctx->d_child_pos.release(); ctx->d_build_temp.release();
     if (ctx->h_word) (void)hipHostFree(ctx->h_word);
     for (auto& sl : ctx->slots) {
-        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.path_state.release(); sl.trace_slots.release();
+        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.trace_slots.release();
         if (sl.h_trace) (void)hipHostFree(sl.h_trace);
         if (sl.trace_copied) (void)hipEventDestroy(sl.trace_copied); sl.cont.release(); sl.flags.release(); sl.frame_params.release(); sl.frame_outs.release();
         if (sl.resolved) (void)hipEventDestroy(sl.resolved);
@@ -781,7 +777,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     if (p->mode == PT_MODE_PATH && p->spp == 0) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: spp must be >= 1");
     const uint32_t count = p->tile_count ? p->tile_count : 1;
     if (p->tile_rank >= count) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: tile_rank >= tile_count");
-    const bool sharded = count > 1;
+    const bool sharded = count > 1 || (p->flags & PT_FLAG_COMPACT) != 0;
     if (sharded && p->mode == PT_MODE_REFERENCE_PACKET) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: the literal packet mode renders whole frames only");
     const bool stats = (p->flags & PT_FLAG_STATS) != 0;
     if (stats && p->mode == PT_MODE_REFERENCE_PACKET) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: no counters in the literal packet mode");

@@ -274,7 +274,7 @@ int pt_group_set_batch(PtGroup* g, uint32_t frames_per_launch) {
 
 int pt_group_render(PtGroup* g, const PtRenderParams* p) {
     if (!g || !p) return gfail(g, PT_ERR_INVALID_ARG, "pt_group_render: null argument");
-    if (p->mode == PT_MODE_REFERENCE_PACKET && g->n > 1) return gfail(g, PT_ERR_INVALID_ARG, "pt_group_render: the literal packet mode renders whole frames only");
+    if (p->mode == PT_MODE_REFERENCE_PACKET) return gfail(g, PT_ERR_INVALID_ARG, "pt_group_render: the literal packet mode renders whole frames only (use a plain context)");
     const bool accum = p->mode == PT_MODE_PATH && p->accumulate != 0;
     if ((g->width != p->width || g->height != p->height || accum != g->accumulating) && (g->queued || g->dirty)) { if (int rc = flush_group(g)) return rc; }
     if (int rc = ensure_buffers(g, p->width, p->height)) return rc;
@@ -283,6 +283,7 @@ int pt_group_render(PtGroup* g, const PtRenderParams* p) {
     const uint32_t j = accum ? 0u : g->queued;
     PtRenderParams q = *p;
     q.tile_count = g->n;
+    q.flags |= PT_FLAG_COMPACT;                 // a one-member group goes through the same compact buffer / gather / de-interleave path
     for (uint32_t r = 0; r < g->n; ++r) {
         q.tile_rank = r;
         G_PT(g, r, pt_set_compact_buffer(g->ctx[r], g->compact[g->set][r] + size_t(j) * g->stride, g->stride));

@@ -8,17 +8,12 @@
 #define PT_KMODE_PATH      2
 
 // megakernel tuning knobs (overridable with -D at build time)
-#ifndef PT_FETCH_DMA
-#define PT_FETCH_DMA 0             // 1: records are fetched by quad-cooperative direct-to-LDS loads (4 KB landing zone per wavefront); 0: four dwordx4 loads per lane
-#endif
 #ifndef PT_SHORT_STACK
-#define PT_SHORT_STACK (PT_FETCH_DMA ? 8 : 12)   // LDS stack entries per lane (8 B each); deeper entries spill to global scratch
+#define PT_SHORT_STACK 12          // LDS stack entries per lane (8 B each); deeper entries spill to global scratch
 #endif
 #ifndef PT_MEGA_WAVES_PER_SIMD
-#define PT_MEGA_WAVES_PER_SIMD (PT_FETCH_DMA ? 5 : 6)   // register budget: resident wavefronts per SIMD the kernel is compiled for
+#define PT_MEGA_WAVES_PER_SIMD 6   // resident 256-thread blocks per CU = waves per SIMD
 #endif
-#define PT_LAND_STRIDE 1040        // bytes between the landing zones of the four fetch instructions (1024 + 16: the owners' 128-bit reads are conflict-free)
-#define PT_MEGA_LDS_BYTES (PT_SHORT_STACK * 512 + (PT_FETCH_DMA ? 4 * PT_LAND_STRIDE : 0))
 #ifndef PT_FRAME_SLOTS
 #define PT_FRAME_SLOTS 3            // whole frames whose trace phases may be in flight at once (side streams); tile-sharded frames use 8
 #endif
@@ -39,20 +34,6 @@
 #endif
 #ifndef PT_FILL_THRESHOLD
 #define PT_FILL_THRESHOLD 8        // regenerate when this many lanes of a wavefront are without a path
-#endif
-
-// second-generation megakernel (pt_trace2.hip: two ray slots per lane)
-#ifndef PT2_SHORT_STACK
-#define PT2_SHORT_STACK 8          // LDS stack entries per slot and lane (two slots: 8 KB per wavefront)
-#endif
-#ifndef PT2_WAVES_PER_SIMD
-#define PT2_WAVES_PER_SIMD 5       // 20 single-wave workgroups per CU: 160 KB of LDS
-#endif
-#ifndef PT2_SERVICE_THRESHOLD
-#define PT2_SERVICE_THRESHOLD 32   // slots (of 128 per wavefront) waiting for a shade / new sample before a service pass runs
-#endif
-#ifndef PT2_LEAF_THRESHOLD
-#define PT2_LEAF_THRESHOLD 24      // slots waiting at a leaf before a triangle step runs
 #endif
 
 namespace ptk {
@@ -124,7 +105,6 @@ struct RenderArgs {
     const FrameParams* frames; float4* const* outs;     // device arrays of the frame slot, filled by launch_frame_params
     uint32_t  num_frames, batches_per_frame;
     uint32_t  prime;            // 1: launch_trace must zero the control block and prefill the samples itself
-    uint4*    path_state;       // trace2: per wavefront 2 slots x 4 quarters x 64 lanes x 16 B of per-path state (pt_trace2.hip)
 };
 
 hipError_t launch_render(const RenderArgs& args, int kmode, bool stats, hipStream_t stream);
@@ -134,9 +114,6 @@ hipError_t launch_prime(uint32_t* queue, float4* samples, uint32_t n_samples, hi
 // per-frame parameters and output targets of a launch into the slot's device arrays (asynchronous: the data travels as kernel arguments)
 hipError_t launch_frame_params(const FrameParams* frames, float4* const* outs, uint32_t n, FrameParams* d_frames, float4** d_outs, hipStream_t stream);
 hipError_t launch_resolve(const RenderArgs& args, hipStream_t stream);
-hipError_t launch_trace2(const RenderArgs& args, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1);
-uint32_t trace2_grid(int num_cus);              // single-wave workgroups that are resident at once
-uint32_t trace2_spill_entries();                // deep stack entries per lane (both slots)
 uint32_t megakernel_grid(int num_cus);
 uint32_t megakernel_block();
 // refit = false leaves the internal BVH2 nodes without bounds (the BVH4 collapse does not read them); launch_lbvh2_refit adds them

@@ -46,10 +46,7 @@ constexpr uint32_t kShadowBit = 1u << 16, kContBit = 1u << 17;
 template <bool STATS, bool CONT>
 __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_paths_kernel(const RenderArgs A) {
     __shared__ unsigned long long lds_stack[PT_MEGA_BLOCK / 64][kShort][64];
-#if PT_FETCH_DMA
-    static_assert(PT_MEGA_BLOCK == 64, "the landing zone is per wavefront");
-    __shared__ __attribute__((aligned(16))) char lds_land[4 * PT_LAND_STRIDE];
-#endif
+
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     unsigned long long* const stk = &lds_stack[wave][0][lane];          // entry i at stk[i * 64]: (tmin bits << 32) | ref
     unsigned long long* const spill = (unsigned long long*)A.spill + ((size_t)blockIdx.x * PT_MEGA_BLOCK + threadIdx.x);   // entry j at spill[j * spill_stride]
@@ -278,39 +275,6 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
         // lane can make progress on nodes); each lane's own visit sequence is unchanged.
         const unsigned long long m_leaf = __ballot(phase == kPhaseTrav && (S.cur & kLeaf) != 0u);
         const bool do_leaf = (uint32_t)__popcll(m_leaf) >= A.leaf_threshold || m_leaf == m_trav;
-#if PT_FETCH_DMA
-        // Record fetch, all 64 lanes (EXEC is full here).  A lane's record -- the 64 B of an internal node or the 48 B of a triangle,
-        // whichever it stands at -- is fetched by its QUAD: in instruction k the four lanes of a quad load the four 16-byte pieces of
-        // the record wanted by the quad's lane k, straight into LDS (global_load_lds_dwordx4: landing zone k, 16 bytes per lane), and
-        // the owner reads its 64 bytes back.  The texture path then sees 16 coalesced 64-byte accesses per instruction instead of 64
-        // scattered 16-byte ones (tools/probes/gather64.hip: 2.1 times the gather rate; the kernel was bound by exactly that unit,
-        // profiles/README.md).  Lanes that do not step ask for the first record of the arena.
-        const bool stepping = phase == kPhaseTrav && (do_leaf || (S.cur & kLeaf) == 0u);
-        uint4 n0, n1, n2, n3;
-        {
-            const bool leaf_f = (S.cur & kLeaf) != 0u;
-            const uint32_t ti_f = S.cur & 0x7fffffffu;
-            uint32_t my_off = leaf_f ? ((ti_f < A.num_tris) ? ti_f * 48u : 0u) : A.node_off + S.cur * 64u;
-            if (!stepping) my_off = 0u;
-            const uint32_t piece = (lane & 3u) * 16u;
-            const char* const base_ptr = (const char*)A.scene;
-#define PT_DMA_K(K) { const uint32_t o_k = (uint32_t)__builtin_amdgcn_mov_dpp((int)my_off, (K) * 0x55, 0xf, 0xf, true) + piece;   /* quad_perm:[K,K,K,K] */ \
-                      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_ptr + o_k), \
-                                                       (__attribute__((address_space(3))) void*)(lds_land + (K) * PT_LAND_STRIDE), 16, 0, 0); }
-            PT_DMA_K(0) PT_DMA_K(1) PT_DMA_K(2) PT_DMA_K(3)
-#undef PT_DMA_K
-            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): the four pieces of every record have landed
-            asm volatile("" ::: "memory");
-            const uint4* mine = (const uint4*)(lds_land + (lane & 3u) * PT_LAND_STRIDE + (lane >> 2) * 64u);
-            n0 = mine[0]; n1 = mine[1]; n2 = mine[2]; n3 = mine[3];
-        }
-        if (stepping) {
-            bool need_pop = false;
-            Ray r; r.o = S.o; r.d = S.d; r.inv = S.inv;
-            const bool at_leaf = (S.cur & kLeaf) != 0u;
-            const uint32_t ti = S.cur & 0x7fffffffu;
-            const bool tri_ok = ti < A.num_tris;
-#else
         if (phase == kPhaseTrav && (do_leaf || (S.cur & kLeaf) == 0u)) {
             bool need_pop = false;
             Ray r; r.o = S.o; r.d = S.d; r.inv = S.inv;
@@ -326,7 +290,6 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
             // keep the four loads here: without this the compiler sinks them into the two branches again
             asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z), "+v"(n1.w),
                               "+v"(n2.x), "+v"(n2.y), "+v"(n2.z), "+v"(n2.w), "+v"(n3.x), "+v"(n3.y), "+v"(n3.z), "+v"(n3.w));
-#endif
             if (at_leaf) {
                 if (tri_ok) {
                     const float4 a = make_float4(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z), __uint_as_float(n0.w));
@@ -582,11 +545,7 @@ hipError_t launch_prime(uint32_t* queue, float4* samples, uint32_t n_samples, hi
     return hipGetLastError();
 }
 
-// grid = residency: what the register budget (waves per SIMD) and the LDS (160 KB per CU) admit
-uint32_t megakernel_grid(int num_cus) {
-    const uint32_t by_regs = PT_MEGA_WAVES_PER_SIMD * (256 / PT_MEGA_BLOCK), by_lds = 163840u / ((PT_MEGA_LDS_BYTES + 255u) / 256u * 256u) / (PT_MEGA_BLOCK / 64);
-    return (uint32_t)num_cus * (by_regs < by_lds ? by_regs : by_lds);
-}
+uint32_t megakernel_grid(int num_cus) { return (uint32_t)num_cus * PT_MEGA_WAVES_PER_SIMD * (256 / PT_MEGA_BLOCK); }
 uint32_t megakernel_block() { return PT_MEGA_BLOCK; }
 
 

@@ -38,12 +38,19 @@ class PathTracer {
       spp: o.spp || 1, maxBounces: o.maxBounces || 0, seed: o.seed === undefined ? 1 : o.seed,
       accumulate: !!o.accumulate, stats: !!o.stats, bruteForce: !!o.bruteForce,
     };
+    // Several GPUs, still one image per render(): `gpus: N` (devices 0..N-1) or `devices: [..]` makes this PathTracer drive a
+    // group of contexts -- pixel tiles interleaved over the GPUs, gathered on the first one over RCCL (pt_group_*, include/mi355pt.h).
+    // `transport: "copy"` swaps the collective for peer copies (members may then share a GPU: rehearsals on a one-GPU machine).
+    this.groupDevices = o.devices ? Int32Array.from(o.devices) : (o.gpus && o.gpus > 1 ? Int32Array.from({ length: o.gpus }, (_, i) => i) : null);
+    this.groupTransport = o.transport === "copy" ? 1 : 0;
+    this.group = null;
     this._hasBVH = false;
   }
 
-  // :97-102 (adapter/device/shaders/buffers/pipelines) -> one native context on one GPU
+  // :97-102 (adapter/device/shaders/buffers/pipelines) -> one native context per GPU
   async initialize() {
-    this.device = native().create(this.options.device);
+    if (this.groupDevices) { this.group = native().groupCreate(this.groupDevices, this.groupTransport); this.device = this.group; }
+    else this.device = native().create(this.options.device);
   }
 
   computeBVH2Sizing(numTris) { return native().computeBVH2Sizing(numTris); }      // :227
@@ -54,7 +61,7 @@ class PathTracer {
   }
 
   async readBVH2(bytes) {                        // :485 -> fresh Uint32Array copy
-    return native().readBVH2(this.device, bytes);
+    return this.group ? native().groupReadBVH2(this.group, bytes) : native().readBVH2(this.device, bytes);
   }
 
   collapseLBVH2ToBVH4(bvh2U32, numTris) {        // :506 -> { bvh4U32, numNodes4 }
@@ -64,8 +71,8 @@ class PathTracer {
   async buildBVH(trianglesData) {                // :671-749
     if (!this.device) return;                    // `if (!device) return`, :673
     const t0 = Date.now();
-    native().setTriangles(this.device, trianglesData);
-    native().buildBVH(this.device);
+    if (this.group) { native().groupSetTriangles(this.group, trianglesData); native().groupBuildBVH(this.group); }
+    else { native().setTriangles(this.device, trianglesData); native().buildBVH(this.device); }
     this._hasBVH = true;
     console.log("BVH Build Time:", Date.now() - t0, "ms");   // :745-748 prints timings
   }
@@ -77,6 +84,7 @@ class PathTracer {
 
   // config C1 extension: brute-force scene = uploaded triangles + analytic spheres, no BVH
   setBruteForceScene(trianglesData, spheresXYZR) {
+    if (this.group) throw new Error("brute-force scenes (config C1) render on one GPU");
     this.trianglesData = trianglesData;
     native().setTriangles(this.device, trianglesData);
     native().setSpheres(this.device, spheresXYZR);
@@ -84,8 +92,8 @@ class PathTracer {
   }
 
   // install a prebuilt BVH (data/BVH2.bin or data/BVH4_wide.bin) instead of rebuilding
-  setBVH2(bvh2U32) { native().setBVH2(this.device, bvh2U32); this._hasBVH = true; }
-  setBVH4(bvh4U32) { native().setBVH4(this.device, bvh4U32); this._hasBVH = true; }
+  setBVH2(bvh2U32) { if (this.group) native().groupSetBVH2(this.group, bvh2U32); else native().setBVH2(this.device, bvh2U32); this._hasBVH = true; }
+  setBVH4(bvh4U32) { if (this.group) native().groupSetBVH4(this.group, bvh4U32); else native().setBVH4(this.device, bvh4U32); this._hasBVH = true; }
 
   async render() {                               // :756-822
     if (!this._hasBVH) return;                   // `if (!this.buffers.BVH) return`, :757
@@ -98,7 +106,8 @@ class PathTracer {
       this.cameraQuaternion[0], this.cameraQuaternion[1], this.cameraQuaternion[2], this.cameraQuaternion[3],
       this.frameCount, 0, 0, 0,
     ]);
-    native().render(this.device, UBO, this.options);   // asynchronous on the GPU, like queue.submit (:821)
+    if (this.group) native().groupRender(this.group, UBO, this.options);   // every GPU traces its tiles; the gather follows on their streams
+    else native().render(this.device, UBO, this.options);                  // asynchronous on the GPU, like queue.submit (:821)
   }
 
   setCameraPosition(x, y, z) { this.cameraPosition = [x, y, z]; }           // :824
@@ -106,17 +115,24 @@ class PathTracer {
   setFrameCount(frameCount) { this.frameCount = frameCount; }               // :832
 
   // queue `n` (1..256) consecutive render() calls into one persistent GPU launch; read-backs flush a partial batch
-  setBatch(n) { native().setBatch(this.device, n); }
-  flush() { native().flush(this.device); }
+  setBatch(n) { if (this.group) native().groupSetBatch(this.group, n); else native().setBatch(this.device, n); }
+  flush() { if (this.group) native().groupFlush(this.group); else native().flush(this.device); }
 
   // ---- results (the reference presents to a canvas; a Node host reads them back) ----
-  readRadiance() { return native().readRadiance(this.device, this.canvas.width, this.canvas.height); }
-  readRGBA8() { return native().readRGBA8(this.device, this.canvas.width, this.canvas.height); }      // outputTex equivalent, :163-172
-  readTonemapped(fromRGBA8) { return native().readTonemapped(this.device, this.canvas.width, this.canvas.height, fromRGBA8 !== false); }  // tonemapper.wgsl
-  lastRenderMs() { return native().lastRenderMs(this.device); }
-  getStats() { return native().getStats(this.device); }
-  synchronize() { native().synchronize(this.device); }
-  destroy() { if (this.device) { native().destroy(this.device); this.device = null; } }
+  readRadiance() { const w = this.canvas.width, h = this.canvas.height; return this.group ? native().groupReadRadiance(this.group, w, h) : native().readRadiance(this.device, w, h); }
+  readRGBA8() { const w = this.canvas.width, h = this.canvas.height; return this.group ? native().groupReadRGBA8(this.group, w, h) : native().readRGBA8(this.device, w, h); }      // outputTex equivalent, :163-172
+  readTonemapped(fromRGBA8) {                                                                                                      // tonemapper.wgsl
+    const w = this.canvas.width, h = this.canvas.height, q = fromRGBA8 !== false;
+    return this.group ? native().groupReadTonemapped(this.group, w, h, q) : native().readTonemapped(this.device, w, h, q);
+  }
+  lastRenderMs() { if (this.group) throw new Error("lastRenderMs: per-context timing; not available on a group"); return native().lastRenderMs(this.device); }
+  getStats() { if (this.group) throw new Error("getStats: per-context counters; not available on a group"); return native().getStats(this.device); }
+  synchronize() { if (this.group) native().groupSynchronize(this.group); else native().synchronize(this.device); }
+  gpuCount() { return this.group ? native().groupSize(this.group) : 1; }
+  destroy() {
+    if (this.group) { native().groupDestroy(this.group); this.group = null; this.device = null; }
+    else if (this.device) { native().destroy(this.device); this.device = null; }
+  }
 }
 
 module.exports = { PathTracer, MODE_REFERENCE_PACKET, MODE_REFERENCE, MODE_PATH, native };

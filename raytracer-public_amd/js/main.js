@@ -10,6 +10,7 @@
 //
 //   node raytracer-public_amd/js/main.js [--frames N] [--width W --height H] [--mode 0|1|2]
 //        [--spp S --bounces B --seed K] [--glb path] [--tris N] [--batch F] [--out frame.ppm] [--dump data/BVH2.bin]
+//        [--gpus N [--transport copy] | --devices 0,0,0]     one image per render() from N GPUs (pixel tiles, RCCL gather)
 "use strict";
 const fs = require("fs");
 const path = require("path");
@@ -21,10 +22,13 @@ function arg(name, dflt) { const i = process.argv.indexOf("--" + name); return i
 async function main() {
   const canvas = { width: Number(arg("width", 1920)), height: Number(arg("height", 1080)) };   // index.html:10
   const mode = Number(arg("mode", PT.MODE_REFERENCE));
-  const pathTracer = new PT.PathTracer(canvas, { mode: mode, spp: Number(arg("spp", 4)), maxBounces: Number(arg("bounces", 8)), seed: Number(arg("seed", 1)) });
+  const devices = arg("devices", null);
+  const pathTracer = new PT.PathTracer(canvas, { mode: mode, spp: Number(arg("spp", 4)), maxBounces: Number(arg("bounces", 8)), seed: Number(arg("seed", 1)),
+                                                 gpus: Number(arg("gpus", 1)), devices: devices ? devices.split(",").map(Number) : null, transport: arg("transport", "rccl") });
   const camera = { position: [0, 0, 2.5], rotation: [0, 0, 0, 1] };                             // src/main.js:10-14
 
   await pathTracer.initialize();
+  if (pathTracer.gpuCount() > 1) console.log("Rendering on", pathTracer.gpuCount(), "GPUs (interleaved 8x8 tiles, gather on the first)");
 
   // ---------- Scene ----------
   const scene = new PTScene.Scene();

@@ -268,31 +268,35 @@ static napi_value fn_scene_info(napi_env env, napi_callback_info info) {
 
 /* ---- the hot path ------------------------------------------------------------------ */
 
+/* argv: the 16-float UBO exactly as PathTracer.js:764-787 packs it + the extension options */
+static int params_from_ubo(napi_env env, napi_value ubo_v, napi_value opt, PtRenderParams* p) {
+    void* u; size_t len; if (!get_typed(env, ubo_v, napi_float32_array, &u, &len)) return 0;
+    if (len < 16) { napi_throw_range_error(env, NULL, "UBO must hold 16 floats"); return 0; }
+    const float* ubo = (const float*)u;
+    memset(p, 0, sizeof *p);
+    p->width = (uint32_t)ubo[0]; p->height = (uint32_t)ubo[1];                  /* u32(ubo.resolution.xy), renderer.wgsl:357 */
+    p->focal = ubo[2]; p->aspect = ubo[3];
+    p->cam_pos[0] = ubo[4]; p->cam_pos[1] = ubo[5]; p->cam_pos[2] = ubo[6];
+    p->num_tris = (uint32_t)ubo[7];                                             /* u32(camPosNumTris.w), renderer.wgsl:398 */
+    p->cam_quat[0] = ubo[8]; p->cam_quat[1] = ubo[9]; p->cam_quat[2] = ubo[10]; p->cam_quat[3] = ubo[11];
+    p->frame = (uint32_t)ubo[12];
+    p->mode = prop_u32(env, opt, "mode", PT_MODE_REFERENCE);
+    p->spp = prop_u32(env, opt, "spp", 1);
+    p->max_bounces = prop_u32(env, opt, "maxBounces", 0);
+    p->seed = prop_u32(env, opt, "seed", 1);
+    p->accumulate = prop_u32(env, opt, "accumulate", 0);
+    p->tile_rank = prop_u32(env, opt, "tileRank", 0);
+    p->tile_count = prop_u32(env, opt, "tileCount", 1);
+    p->flags = (prop_u32(env, opt, "stats", 0) ? PT_FLAG_STATS : 0u) | (prop_u32(env, opt, "simpleKernel", 0) ? PT_FLAG_SIMPLE_KERNEL : 0u) |
+               (prop_u32(env, opt, "bruteForce", 0) ? PT_FLAG_BRUTE_FORCE : 0u);
+    (void)prop_f64;
+    return 1;
+}
+
 static napi_value fn_render(napi_env env, napi_callback_info info) {          /* PathTracer.render() compute pass, PathTracer.js:756-802 */
     napi_value argv[3]; if (!get_args(env, info, 3, argv)) return NULL;
     PtContext* ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
-    /* argv[1]: the 16-float UBO exactly as PathTracer.js:764-787 packs it; argv[2]: extension options */
-    void* u; size_t len; if (!get_typed(env, argv[1], napi_float32_array, &u, &len)) return NULL;
-    if (len < 16) { napi_throw_range_error(env, NULL, "UBO must hold 16 floats"); return NULL; }
-    const float* ubo = (const float*)u;
-    PtRenderParams p; memset(&p, 0, sizeof p);
-    p.width = (uint32_t)ubo[0]; p.height = (uint32_t)ubo[1];                    /* u32(ubo.resolution.xy), renderer.wgsl:357 */
-    p.focal = ubo[2]; p.aspect = ubo[3];
-    p.cam_pos[0] = ubo[4]; p.cam_pos[1] = ubo[5]; p.cam_pos[2] = ubo[6];
-    p.num_tris = (uint32_t)ubo[7];                                              /* u32(camPosNumTris.w), renderer.wgsl:398 */
-    p.cam_quat[0] = ubo[8]; p.cam_quat[1] = ubo[9]; p.cam_quat[2] = ubo[10]; p.cam_quat[3] = ubo[11];
-    p.frame = (uint32_t)ubo[12];
-    napi_value opt = argv[2];
-    p.mode = prop_u32(env, opt, "mode", PT_MODE_REFERENCE);
-    p.spp = prop_u32(env, opt, "spp", 1);
-    p.max_bounces = prop_u32(env, opt, "maxBounces", 0);
-    p.seed = prop_u32(env, opt, "seed", 1);
-    p.accumulate = prop_u32(env, opt, "accumulate", 0);
-    p.tile_rank = prop_u32(env, opt, "tileRank", 0);
-    p.tile_count = prop_u32(env, opt, "tileCount", 1);
-    p.flags = (prop_u32(env, opt, "stats", 0) ? PT_FLAG_STATS : 0u) | (prop_u32(env, opt, "simpleKernel", 0) ? PT_FLAG_SIMPLE_KERNEL : 0u) |
-              (prop_u32(env, opt, "bruteForce", 0) ? PT_FLAG_BRUTE_FORCE : 0u);
-    (void)prop_f64;
+    PtRenderParams p; if (!params_from_ubo(env, argv[1], argv[2], &p)) return NULL;
     PT_CALL(ctx, pt_render(ctx, &p), "pt_render");
     return NULL;
 }
@@ -352,6 +356,133 @@ static napi_value read_u8(napi_env env, napi_callback_info info, int which) {
 static napi_value fn_read_rgba8(napi_env env, napi_callback_info info) { return read_u8(env, info, 1); }       /* outputTex, PathTracer.js:163-172 */
 static napi_value fn_read_tonemapped(napi_env env, napi_callback_info info) { return read_u8(env, info, 2); }  /* tonemapper.wgsl */
 
+
+/* ---- several GPUs, one image per render(): pt_group_* (include/mi355pt.h) --------------------------------------- */
+
+static void finalize_group(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    PtGroup** box = (PtGroup**)data;
+    if (*box) pt_group_destroy(*box);
+    free(box);
+}
+static PtGroup* get_group(napi_env env, napi_value v) {
+    void* p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !*(PtGroup**)p) { napi_throw_type_error(env, NULL, "expected a group handle"); return NULL; }
+    return *(PtGroup**)p;
+}
+static napi_value throw_group(napi_env env, PtGroup* g, int rc, const char* where) {
+    char msg[640];
+    const char* e = pt_group_last_error(g);
+    snprintf(msg, sizeof msg, "%s: libmi355pt error %d: %s", where, rc, e ? e : "");
+    char code[16]; snprintf(code, sizeof code, "PT%d", rc);
+    napi_throw_error(env, code, msg);
+    return NULL;
+}
+#define PTG_CALL(g, call, where) do { int rc__ = (call); if (rc__ != 0) return throw_group(env, (g), rc__, (where)); } while (0)
+
+static napi_value fn_group_create(napi_env env, napi_callback_info info) {    /* (Int32Array devices | number of devices, transport) */
+    napi_value argv[2]; if (!get_args(env, info, 2, argv)) return NULL;
+    bool is_ta = false; napi_is_typedarray(env, argv[0], &is_ta);
+    const int* devs = NULL; uint32_t n = 0;
+    if (is_ta) { void* d; size_t len; if (!get_typed(env, argv[0], napi_int32_array, &d, &len)) return NULL; devs = (const int*)d; n = (uint32_t)len; }
+    else n = get_u32(env, argv[0]);
+    PtGroup** box = (PtGroup**)calloc(1, sizeof(PtGroup*));
+    int rc = pt_group_create(devs, n, get_u32(env, argv[1]), box);
+    if (rc != 0) { free(box); return throw_group(env, NULL, rc, "pt_group_create"); }
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, box, finalize_group, NULL, &ext));
+    return ext;
+}
+static napi_value fn_group_destroy(napi_env env, napi_callback_info info) {
+    napi_value argv[1]; if (!get_args(env, info, 1, argv)) return NULL;
+    void* p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) { PtGroup** box = (PtGroup**)p; if (*box) { pt_group_destroy(*box); *box = NULL; } }
+    return NULL;
+}
+static napi_value fn_group_size(napi_env env, napi_callback_info info) {
+    napi_value argv[1]; if (!get_args(env, info, 1, argv)) return NULL;
+    PtGroup* g = get_group(env, argv[0]); if (!g) return NULL;
+    uint32_t n = 0; PTG_CALL(g, pt_group_size(g, &n), "pt_group_size");
+    napi_value v; NAPI_OK(napi_create_uint32(env, n, &v)); return v;
+}
+static napi_value fn_group_set_triangles(napi_env env, napi_callback_info info) {
+    napi_value argv[2]; if (!get_args(env, info, 2, argv)) return NULL;
+    PtGroup* g = get_group(env, argv[0]); if (!g) return NULL;
+    void* d; size_t len; if (!get_typed(env, argv[1], napi_float32_array, &d, &len)) return NULL;
+    PTG_CALL(g, pt_group_set_triangles(g, (const float*)d, (uint32_t)(len / 9)), "pt_group_set_triangles");
+    return NULL;
+}
+static napi_value fn_group_build_bvh(napi_env env, napi_callback_info info) {
+    napi_value argv[1]; if (!get_args(env, info, 1, argv)) return NULL;
+    PtGroup* g = get_group(env, argv[0]); if (!g) return NULL;
+    PTG_CALL(g, pt_group_build_bvh(g), "pt_group_build_bvh");
+    return NULL;
+}
+static napi_value group_set_bvh(napi_env env, napi_callback_info info, int four) {
+    napi_value argv[2]; if (!get_args(env, info, 2, argv)) return NULL;
+    PtGroup* g = get_group(env, argv[0]); if (!g) return NULL;
+    void* d; size_t len; if (!get_typed(env, argv[1], napi_uint32_array, &d, &len)) return NULL;
+    if (four) PTG_CALL(g, pt_group_set_bvh4(g, (const uint32_t*)d, len), "pt_group_set_bvh4");
+    else PTG_CALL(g, pt_group_set_bvh2(g, (const uint32_t*)d, len), "pt_group_set_bvh2");
+    return NULL;
+}
+static napi_value fn_group_set_bvh4(napi_env env, napi_callback_info info) { return group_set_bvh(env, info, 1); }
+static napi_value fn_group_set_bvh2(napi_env env, napi_callback_info info) { return group_set_bvh(env, info, 0); }
+static napi_value fn_group_read_bvh2(napi_env env, napi_callback_info info) {  /* readBVH2 of rank 0 (every member holds the same buffer) */
+    napi_value argv[2]; if (!get_args(env, info, 2, argv)) return NULL;
+    PtGroup* g = get_group(env, argv[0]); if (!g) return NULL;
+    PtContext* c0 = NULL; PTG_CALL(g, pt_group_context(g, 0, &c0), "pt_group_context");
+    double bytes = get_f64(env, argv[1]);
+    size_t size = bytes < 4 ? 4 : (size_t)bytes;
+    void* out; napi_value ta = make_typed(env, napi_uint32_array, 4, size / 4, &out); if (!ta) return NULL;
+    PT_CALL(c0, pt_read_bvh2(c0, (uint32_t*)out, (size / 4) * 4), "pt_read_bvh2");
+    return ta;
+}
+static napi_value fn_group_set_batch(napi_env env, napi_callback_info info) {
+    napi_value argv[2]; if (!get_args(env, info, 2, argv)) return NULL;
+    PtGroup* g = get_group(env, argv[0]); if (!g) return NULL;
+    PTG_CALL(g, pt_group_set_batch(g, get_u32(env, argv[1])), "pt_group_set_batch");
+    return NULL;
+}
+static napi_value fn_group_render(napi_env env, napi_callback_info info) {
+    napi_value argv[3]; if (!get_args(env, info, 3, argv)) return NULL;
+    PtGroup* g = get_group(env, argv[0]); if (!g) return NULL;
+    PtRenderParams p; if (!params_from_ubo(env, argv[1], argv[2], &p)) return NULL;
+    PTG_CALL(g, pt_group_render(g, &p), "pt_group_render");
+    return NULL;
+}
+static napi_value fn_group_flush(napi_env env, napi_callback_info info) {
+    napi_value argv[1]; if (!get_args(env, info, 1, argv)) return NULL;
+    PtGroup* g = get_group(env, argv[0]); if (!g) return NULL;
+    PTG_CALL(g, pt_group_flush(g), "pt_group_flush");
+    return NULL;
+}
+static napi_value fn_group_sync(napi_env env, napi_callback_info info) {
+    napi_value argv[1]; if (!get_args(env, info, 1, argv)) return NULL;
+    PtGroup* g = get_group(env, argv[0]); if (!g) return NULL;
+    PTG_CALL(g, pt_group_synchronize(g), "pt_group_synchronize");
+    return NULL;
+}
+static napi_value fn_group_read_radiance(napi_env env, napi_callback_info info) {
+    napi_value argv[3]; if (!get_args(env, info, 3, argv)) return NULL;
+    PtGroup* g = get_group(env, argv[0]); if (!g) return NULL;
+    size_t n = (size_t)get_u32(env, argv[1]) * get_u32(env, argv[2]) * 4;
+    void* out; napi_value ta = make_typed(env, napi_float32_array, 4, n, &out); if (!ta) return NULL;
+    PTG_CALL(g, pt_group_read_radiance(g, (float*)out, n), "pt_group_read_radiance");
+    return ta;
+}
+static napi_value group_read_u8(napi_env env, napi_callback_info info, int which) {
+    napi_value argv[4]; if (!get_args(env, info, which == 2 ? 4 : 3, argv)) return NULL;
+    PtGroup* g = get_group(env, argv[0]); if (!g) return NULL;
+    size_t n = (size_t)get_u32(env, argv[1]) * get_u32(env, argv[2]) * 4;
+    void* out; napi_value ta = make_typed(env, napi_uint8_array, 1, n, &out); if (!ta) return NULL;
+    if (which == 1) PTG_CALL(g, pt_group_read_rgba8(g, (uint8_t*)out, n), "pt_group_read_rgba8");
+    else { bool q = true; napi_get_value_bool(env, argv[3], &q); PTG_CALL(g, pt_group_read_tonemapped(g, q ? 1 : 0, (uint8_t*)out, n), "pt_group_read_tonemapped"); }
+    return ta;
+}
+static napi_value fn_group_read_rgba8(napi_env env, napi_callback_info info) { return group_read_u8(env, info, 1); }
+static napi_value fn_group_read_tonemapped(napi_env env, napi_callback_info info) { return group_read_u8(env, info, 2); }
+
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"create", fn_create}, {"destroy", fn_destroy}, {"version", fn_version},
@@ -362,6 +493,10 @@ static napi_value init(napi_env env, napi_value exports) {
         {"setBVH4", fn_set_bvh4}, {"setBVH2", fn_set_bvh2}, {"setSpheres", fn_set_spheres}, {"sceneInfo", fn_scene_info},
         {"render", fn_render}, {"setBatch", fn_set_batch}, {"flush", fn_flush}, {"lastRenderMs", fn_last_ms}, {"synchronize", fn_sync}, {"getStats", fn_stats},
         {"readRadiance", fn_read_radiance}, {"readRGBA8", fn_read_rgba8}, {"readTonemapped", fn_read_tonemapped},
+        {"groupCreate", fn_group_create}, {"groupDestroy", fn_group_destroy}, {"groupSize", fn_group_size},
+        {"groupSetTriangles", fn_group_set_triangles}, {"groupBuildBVH", fn_group_build_bvh}, {"groupSetBVH4", fn_group_set_bvh4}, {"groupSetBVH2", fn_group_set_bvh2},
+        {"groupReadBVH2", fn_group_read_bvh2}, {"groupSetBatch", fn_group_set_batch}, {"groupRender", fn_group_render}, {"groupFlush", fn_group_flush},
+        {"groupSynchronize", fn_group_sync}, {"groupReadRadiance", fn_group_read_radiance}, {"groupReadRGBA8", fn_group_read_rgba8}, {"groupReadTonemapped", fn_group_read_tonemapped},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
         napi_value f;

@@ -1,0 +1,89 @@
+"""pt_group_*: one image per render() from several member contexts inside one process.  On the one-GPU box the members
+share cuda:0 through the diagnostic copy transport (everything but the ncclGather call itself: tile ownership, per-member compact
+buffers, batching, the order on the members' streams, de-interleave); the RCCL transport is exercised with a one-member group."""
+import numpy as np
+import pytest
+
+import orc as orc_mod
+
+pytestmark = pytest.mark.gpu
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+@pytest.fixture
+def scene(rt):
+    return rt.procedural_scene(0, 20000)
+
+
+@pytest.mark.parametrize("members", [2, 3, 8])
+def test_group_of_members_on_one_gpu_equals_the_whole_frame(rt, orc, scene, members):
+    g = rt.Group([0] * members, rt.PT_GROUP_TRANSPORT_COPY)
+    try:
+        assert g.size() == members
+        g.set_triangles(scene)
+        g.build_bvh()
+        one = rt.Context(0)
+        one.set_triangles(scene); one.build_bvh()
+        bvh4 = one.read_bvh4()
+        for (w, h) in ((200, 120), (97, 61)):
+            kw = dict(mode=rt.PT_MODE_PATH, spp=3, max_bounces=4, seed=5)
+            ref, _, _ = orc.render(orc.make_params(w, h, scene.size // 9, mode=orc_mod.MODE_PATH, spp=3, max_bounces=4, seed=5, frame=2), scene, bvh4)
+            g.render(g.make_params(w, h, frame=2, **kw))
+            assert same_bits(g.read_radiance(), ref), (members, w, h)
+            # reference mode goes through the same sharding
+            g.render(g.make_params(w, h, mode=rt.PT_MODE_REFERENCE))
+            one.render(one.make_params(w, h, mode=rt.PT_MODE_REFERENCE))
+            assert same_bits(g.read_radiance(), one.read_radiance())
+        # batches: several frames per launch and collective; the last frame is the result, every frame is traced
+        g.set_batch(4)
+        w, h = 160, 96
+        for f in range(6):                                   # one full batch of 4 and a partial one of 2
+            g.render(g.make_params(w, h, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=9, frame=f))
+        one.render(one.make_params(w, h, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=9, frame=5))
+        assert same_bits(g.read_radiance(), one.read_radiance())
+        # an accumulating sequence keeps its running sums on the members and is gathered when the image is asked for
+        for f in range(5):
+            g.render(g.make_params(w, h, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=9, frame=10 + f, accumulate=True))
+        acc = g.read_radiance()
+        want, _, _ = orc.render(orc.make_params(w, h, scene.size // 9, mode=orc_mod.MODE_PATH, spp=2, max_bounces=3, seed=9, frame=10, accum_frames=5), scene, bvh4)
+        assert same_bits(acc, want)
+        g.set_batch(1)
+        g.render(g.make_params(w, h, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=9, frame=10))      # a plain frame ends the sequence
+        one.render(one.make_params(w, h, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=9, frame=10))
+        assert same_bits(g.read_radiance(), one.read_radiance())
+        one.close()
+    finally:
+        g.close()
+
+
+def test_group_rccl_transport_single_member(rt, scene):
+    # ncclCommInitAll + ncclGather with world size 1: the RCCL calls themselves (librccl is opened here for the first time)
+    g = rt.Group([0], rt.PT_GROUP_TRANSPORT_RCCL)
+    try:
+        g.set_triangles(scene); g.build_bvh()
+        one = rt.Context(0); one.set_triangles(scene); one.build_bvh()
+        g.set_batch(3)
+        for f in range(3):
+            g.render(g.make_params(128, 72, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=4, frame=f))
+        one.render(one.make_params(128, 72, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=4, frame=2))
+        assert same_bits(g.read_radiance(), one.read_radiance())
+        assert g.read_rgba8().shape == (72, 128, 4)
+        one.close()
+    finally:
+        g.close()
+
+
+def test_group_errors(rt):
+    with pytest.raises(rt.PtError):
+        rt.Group([0, 0], rt.PT_GROUP_TRANSPORT_RCCL)        # RCCL needs distinct GPUs
+    with pytest.raises(rt.PtError):
+        rt.Group([99], rt.PT_GROUP_TRANSPORT_COPY)
+    g = rt.Group([0], rt.PT_GROUP_TRANSPORT_COPY)
+    with pytest.raises(rt.PtError):
+        g.render(g.make_params(8, 8))                        # no scene yet
+    with pytest.raises(rt.PtError):
+        g.set_batch(0)
+    g.close()

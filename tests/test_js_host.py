@@ -79,3 +79,36 @@ const path=require('path'); const PT=require(%r); const {Scene}=require(%r);
     img2 = np.fromfile(str(tmp_path / "img2.bin"), np.float32).reshape(96, 160, 4)
     assert np.array_equal(img2.view(np.uint32), ref2.view(np.uint32))
     assert info["rgba0"][3] == 255
+
+
+@pytest.mark.gpu
+def test_node_group_one_image_from_three_members(tmp_path, orc):
+    """js/PathTracer.js with `devices: [0,0,0]` drives a pt_group (three member contexts sharing cuda:0 through the copy transport --
+    RCCL refuses members on one GPU): same call sequence, one image per render(), bit-identical to the oracle; js/main.js --devices too."""
+    import orc as orc_mod
+    glb = os.path.join(HERE, "golden", "dodecahedron.glb")
+    script = r"""
+const PT=require(%r); const {Scene}=require(%r);
+(async()=>{ const log=console.log; console.log=()=>{};
+ const pt=new PT.PathTracer({width:144,height:88},{mode:PT.MODE_PATH,spp:3,maxBounces:4,seed:6,devices:[0,0,0],transport:'copy'});
+ await pt.initialize(); const s=new Scene(); await s.loadGLB(%r,{normalize:true,mode:'cube'}); await pt.setScene(s);
+ const n=(pt.trianglesData.length/9)|0; const b2=await pt.readBVH2(pt.computeBVH2Sizing(n).bytes);
+ pt.setCameraPosition(0.2,-0.1,2.4); pt.setCameraQuaternion(0,0,0,1);
+ pt.setBatch(2); for (let f=1; f<=3; f++) { pt.setFrameCount(f); await pt.render(); }
+ const img=pt.readRadiance();
+ require('fs').writeFileSync(%r, Buffer.from(img.buffer)); require('fs').writeFileSync(%r, Buffer.from(pt.trianglesData.buffer)); require('fs').writeFileSync(%r, Buffer.from(b2.buffer));
+ log(JSON.stringify({n:n, gpus:pt.gpuCount()})); pt.destroy(); })().catch(e=>{console.error(e);process.exit(1);});
+""" % (os.path.join(ROOT, "raytracer-public_amd", "js", "PathTracer.js"), os.path.join(ROOT, "raytracer-public_amd", "js", "Scene.js"),
+       glb, str(tmp_path / "img.bin"), str(tmp_path / "tris.bin"), str(tmp_path / "bvh2.bin"))
+    info = json.loads(subprocess.check_output([NODE, "-e", script], text=True).strip().splitlines()[-1])
+    assert info == {"n": 36, "gpus": 3}
+    tris = np.fromfile(str(tmp_path / "tris.bin"), np.float32)
+    bvh2 = orc.build_lbvh2(tris)
+    assert np.array_equal(np.fromfile(str(tmp_path / "bvh2.bin"), np.uint32), bvh2)
+    bvh4, _ = orc.collapse_bvh4(bvh2, 36)
+    ref, _, _ = orc.render(orc.make_params(144, 88, 36, (0.2, -0.1, 2.4), (0, 0, 0, 1), mode=orc_mod.MODE_PATH, spp=3, max_bounces=4, seed=6, frame=3), tris, bvh4)
+    img = np.fromfile(str(tmp_path / "img.bin"), np.float32).reshape(88, 144, 4)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    out = subprocess.check_output([NODE, os.path.join(ROOT, "raytracer-public_amd", "js", "main.js"), "--devices", "0,0", "--transport", "copy", "--frames", "4", "--mode", "2",
+                                   "--width", "320", "--height", "180", "--tris", "20000", "--dump", str(tmp_path / "d" / "BVH2.bin")], text=True)
+    assert "Rendering on 2 GPUs" in out and "Msamples/s" in out

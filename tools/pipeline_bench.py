@@ -21,9 +21,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 if os.environ.get("PB_RING"): ctx.timing_begin(n)
 t0 = time.perf_counter()
 vary = bool(os.environ.get("PB_VARY"))        # a new frame index (new sample set) every frame, like a progressive render
+solo = bool(os.environ.get("PB_SOLO"))        # wait for every frame before the next one is submitted (latency of a single frame)
 for i in range(n):
     if vary: p.frame = 1000 + i
     ctx.render(p)
+    if solo: ctx.synchronize()
 ctx.synchronize()
 dt = time.perf_counter() - t0
 if os.environ.get("PB_RING"):

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Reduce the rocprofv3 passes of tools/pmc_bench.sh: per-frame counter totals of bench.py's TIMED trace_paths_kernel launches."""
+import collections, csv, glob, hashlib, json, os, sys
+
+out_dir, command = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = "trace_paths_kernel<false, false>"
+
+
+def source_tag():
+    h = hashlib.sha256()
+    for f in ("pt_megakernel.hip", "pt_device.h", "pt_kernels.h"):
+        h.update(open(os.path.join(ROOT, "raytracer-public_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+per_frame, launches_seen = collections.OrderedDict(), {}
+steps = None
+for p in sorted(glob.glob(os.path.join(out_dir, "pass*/"))):
+    n = os.path.basename(os.path.dirname(p))[4:]
+    log = json.load(open(os.path.join(out_dir, "launch_log_pass%s.json" % n)))
+    steps = log["steps"]
+    timed = [k for k, (tag, nf) in enumerate(log["launches"]) if tag == "timed"]
+    rows = collections.OrderedDict()          # counter -> {dispatch id: value}; dispatch ids grow in submission order
+    for f in glob.glob(p + "**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if KERNEL not in row.get("Kernel_Name", "").replace("false,false", "false, false"):
+                continue
+            rows.setdefault(row["Counter_Name"], {})[int(row["Dispatch_Id"])] = float(row["Counter_Value"])
+    for name, by_id in rows.items():
+        vals = [by_id[k] for k in sorted(by_id)]
+        if len(vals) != len(log["launches"]):
+            print("pass %s: %d dispatches of %s, launch log has %d -- skipped" % (n, len(vals), KERNEL, len(log["launches"])))
+            continue
+        per_frame[name] = sum(vals[k] for k in timed) / steps
+        launches_seen[name] = len(timed)
+stats = {}
+for f in glob.glob(os.path.join(out_dir, "trace/**/*kernel_stats.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "trace_paths_kernel" in row["Name"] or "resolve_kernel" in row["Name"]:
+            stats[row["Name"]] = {k: row[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs") if k in row}
+    os.system("cp %s %s" % (f, os.path.join(out_dir, "kernel_stats.csv")))
+res = {"command": command, "source_tag": source_tag(), "kernel": KERNEL, "steps": steps,
+       "frames_per_launch": steps / max(launches_seen.get("SQ_INSTS_VALU", 1), 1), "timed_launches": launches_seen.get("SQ_INSTS_VALU"),
+       "per_frame": per_frame, "kernel_stats": stats,
+       "how": "tools/pmc_bench.sh: one rocprofv3 --pmc pass per counter group over the command above; the timed launches are identified by "
+              "position from bench.py's own launch log; SQ_* cycle counters are in units of 4 cycles; FETCH_SIZE / WRITE_SIZE in KB"}
+json.dump(res, open(os.path.join(out_dir, "pmc_bench.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))
