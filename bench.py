@@ -213,10 +213,10 @@ def main():
     # Frames are submitted in batches: the library traces `batch` consecutive frames with one persistent
     # launch (pt_set_batch), which amortises the sparse tail of a frame -- essential for the small per-GPU
     # shares of a sharded run.  The RCCL gather then moves one batch at a time (fewer, larger collectives).
-    # At least two launches per timed region so that consecutive launches overlap; up to 32 frames of work per launch
-    # (256 frames = pt_set_batch's maximum).
     fixed_batch = bool(os.environ.get("PT_BENCH_BATCH"))
-    batch = int(os.environ.get("PT_BENCH_BATCH", "0")) or (args.steps + 1) // 2
+    # A run of up to 32 frames of work is ONE launch (its sparse tail is paid once); longer runs use launches of 32 frames of work,
+    # which overlap on the context's side streams.
+    batch = int(os.environ.get("PT_BENCH_BATCH", "0")) or args.steps
     batch = max(1, min(32 * world, 256, batch))
     launch_log = []                  # (tag, frames) of every un-instrumented megakernel launch, in submission order
 

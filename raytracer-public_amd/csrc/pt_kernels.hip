@@ -441,17 +441,19 @@ __global__ __launch_bounds__(256) void lbvh2_leaves_kernel(uint32_t* bvh2, const
         p[3] = 0u; p[4] = 0u; p[5] = kLeaf | (ti & 0x7fffffffu);
     }
     if (!REFIT || internal == 0u) return;
-    // bottom-up refit (BVHBuilder.wgsl:242-275).  The reference has no fence between a child's
-    // bounds store and the flag increment; here the stores are agent-scope, a release fence
-    // precedes the atomic and an acquire fence follows it (MI355X L2s are per XCD).
+    // bottom-up refit (BVHBuilder.wgsl:242-275): the second thread to arrive at a node unions its children's bounds.  The
+    // reference orders nothing between a child's bounds store and the arrival count.  Here every bounds word is written and
+    // read with agent-scope accesses (write-through stores, L1-bypassing loads: the 8 per-XCD L2s are not coherent with each
+    // other for plain accesses), a thread's stores have left the CU (s_waitcnt vmcnt(0)) before it counts itself in, and the
+    // reads of the sibling's bounds depend on the returned count -- no cache write-back / invalidate per step (two
+    // __threadfence() per step made this walk 4x as long as the whole rest of the build).
     uint32_t cur = node;
     for (;;) {
         const uint32_t par = parent[cur];
         if (par == kInvalidRef || par >= internal) break;
-        __threadfence();
-        const uint32_t old = atomicAdd(&flags[par], 1u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t old = __hip_atomic_fetch_add(&flags[par], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == 0u) break;
-        __threadfence();
         const uint32_t* pp = bvh2 + 1 + (size_t)par * 6;
         const uint32_t l = pp[3], r = pp[4];
         const uint32_t* lp = bvh2 + 1 + (size_t)l * 6; const uint32_t* rp = bvh2 + 1 + (size_t)r * 6;

@@ -192,6 +192,9 @@ def test_c2_full_size_every_pixel_and_counters(rt, orc, dragon_full):
     counter against the oracle (16 host threads)."""
     c = dragon_full
     bvh4 = c.read_bvh4()
+    # the LBVH2 of all 871,414 triangles incl. the bottom-up refit of the internal bounds (pt_read_bvh2), word for word
+    morton, tri_index = rt.morton_sort(c._tris)
+    assert np.array_equal(c.read_bvh2(), orc.build_lbvh2(c._tris, morton, tri_index))
     w, h = 1920, 1080
     ref, ost = orc.render_mt(orc.make_params(w, h, 871414, mode=orc_mod.MODE_PATH, spp=4, max_bounces=8, seed=1), c._tris, bvh4)
     c.render(c.make_params(w, h, mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, seed=1, stats=True))

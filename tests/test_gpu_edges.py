@@ -186,7 +186,7 @@ def test_bench_single_gpu_contract_line():
     rf = r["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_busy_ms", "algorithmic"):
         assert k in rf, k
-    assert rf["frames_per_launch"] == 6.0 and rf["launches"] == 2
+    assert rf["frames_per_launch"] == 12.0 and rf["launches"] == 1
     # the trace kernel is busy for most of the timed region and never longer than it
     assert 0.3 * r["ms_per_step"] * 12 < rf["kernel_busy_ms"] <= r["ms_per_step"] * 12 * 1.02
     assert rf["frac"] is None or 0.0 < rf["frac"] <= 1.0
