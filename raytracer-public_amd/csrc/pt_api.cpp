@@ -141,18 +141,27 @@ int bind(PtContext* ctx) {
     return PT_OK;
 }
 
+// Triangle records, then one all-zero record (what a leaf with an out-of-range triangle index points at: never hit), then padding
+// to a multiple of 64 B that also covers the 64-byte fetch of the last record.
+uint64_t tri_region_bytes(uint32_t num_tris) { return ((uint64_t(num_tris) * 48u + 48u + 64u + 63u) / 64u) * 64u; }
+
 // Room for `num_tris` triangle records and `nodes` wide nodes; triangle records that are already there survive a regrowth.
 int ensure_scene(PtContext* ctx, uint32_t num_tris, uint64_t nodes) {
-    const uint64_t tri_bytes = ((uint64_t(num_tris) * 48u + 64u + 63u) / 64u) * 64u;      // + 64 B: the 64-byte fetch of the last record over-reads
+    const uint64_t tri_bytes = tri_region_bytes(num_tris);
     const uint64_t need = tri_bytes + (nodes + 1u) * 64u;
     if (need >= 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "scene too large: triangle records and BVH nodes are addressed by 32-bit byte offsets (4 GiB)");
-    if (ctx->d_scene.ptr && ctx->node_off == tri_bytes && ctx->node_cap >= nodes) { ctx->scene_tris = num_tris; return PT_OK; }
+    if (ctx->d_scene.ptr && ctx->node_off == tri_bytes && ctx->node_cap >= nodes) {
+        if (ctx->scene_tris != num_tris)      // another triangle count in the same region: the never-hit record moves
+            PT_HIP(ctx, hipMemset((char*)ctx->d_scene.ptr + uint64_t(num_tris) * 48u, 0, tri_bytes - uint64_t(num_tris) * 48u));
+        ctx->scene_tris = num_tris; return PT_OK;
+    }
     const uint64_t cap_nodes = nodes + nodes / 8u + 16u;
     uint4* fresh = nullptr;
     PT_HIP(ctx, hipMalloc((void**)&fresh, tri_bytes + (cap_nodes + 1u) * 64u));
     if (ctx->d_scene.ptr && ctx->scene_tris == num_tris && num_tris)          // the records of the current triangles move along
         PT_HIP(ctx, hipMemcpy(fresh, ctx->d_scene.ptr, uint64_t(num_tris) * 48u, hipMemcpyDeviceToDevice));
     if (ctx->d_scene.ptr) (void)hipFree(ctx->d_scene.ptr);
+    PT_HIP(ctx, hipMemset((char*)fresh + uint64_t(num_tris) * 48u, 0, tri_bytes - uint64_t(num_tris) * 48u));      // the never-hit record and the padding
     ctx->d_scene.ptr = fresh; ctx->d_scene.cap = size_t((tri_bytes + (cap_nodes + 1u) * 64u) / 16u);
     ctx->node_off = tri_bytes; ctx->node_cap = cap_nodes; ctx->scene_tris = num_tris;
     return PT_OK;
@@ -160,10 +169,11 @@ int ensure_scene(PtContext* ctx, uint32_t num_tris, uint64_t nodes) {
 
 int upload_wide(PtContext* ctx, const uint32_t* bvh4, uint64_t words) {
     pt::WideBvh w; std::string err;
-    if (!pt::build_wide_bvh(bvh4, words, w, err)) return fail(ctx, PT_ERR_BAD_BVH, err);
+    const uint32_t tris_now = ctx->have_tris ? ctx->num_tris : 0u;
+    if (!pt::build_wide_bvh(bvh4, words, tris_now, uint32_t(tri_region_bytes(tris_now) / 16u), w, err)) return fail(ctx, PT_ERR_BAD_BVH, err);
     PT_HIP(ctx, ctx->d_bvh4.ensure(words));
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh4.ptr, bvh4, words * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = ensure_scene(ctx, ctx->have_tris ? ctx->num_tris : 0u, w.nodes.size())) return rc;
+    if (int rc = ensure_scene(ctx, tris_now, w.nodes.size())) return rc;
     if (!w.nodes.empty())
         PT_HIP(ctx, hipMemcpyAsync(ctx->wide(), w.nodes.data(), w.nodes.size() * sizeof(pt::WideNode), hipMemcpyHostToDevice, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die at return
@@ -710,14 +720,14 @@ int pt_build_bvh(PtContext* ctx) {
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t internal = tail[0] + tail[1];
     if (int rc = ensure_scene(ctx, n, internal)) return rc;
-    PT_HIP(ctx, ptk::launch_wide_nodes(B, ctx->d_bvh4.ptr, m, ctx->wide(), ctx->stream));
+    PT_HIP(ctx, ptk::launch_wide_nodes(B, ctx->d_bvh4.ptr, m, ctx->wide(), n, uint32_t(ctx->node_off / 16u), ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     pt::WideBvh meta;
     meta.num_nodes4 = m;
     meta.root_box[0] = root[0]; meta.root_box[1] = root[1]; meta.root_box[2] = root[2];
     meta.root_degenerate = pt::half_to_float(root[0] & 0xffffu) > pt::half_to_float(root[1] >> 16) || pt::half_to_float(root[0] >> 16) > pt::half_to_float(root[2] & 0xffffu) ||
                            pt::half_to_float(root[1] & 0xffffu) > pt::half_to_float(root[2] >> 16);
-    meta.root_ref = (root[7] & pt::kLeafFlag) ? (pt::kLeafFlag | (root[7] & 0x7fffffffu)) : 0u;
+    meta.root_ref = (root[7] & pt::kLeafFlag) ? pt::packed_leaf_ref(root[7] & 0x7fffffffu, n) : uint32_t(ctx->node_off / 16u);
     ctx->wide_meta = meta;
     ctx->num_nodes4 = m;
     ctx->have_bvh = true;

@@ -268,21 +268,23 @@ __device__ __forceinline__ bool box_degenerate(uint32_t w0, uint32_t w1, uint32_
     return half_exact(w0 & 0xffffu) > half_exact(w1 >> 16) || half_exact(w0 >> 16) > half_exact(w2 & 0xffffu) || half_exact(w1 & 0xffffu) > half_exact(w2 >> 16);
 }
 
-__global__ __launch_bounds__(256) void wide_nodes_kernel(const uint32_t* __restrict__ bvh4, uint32_t m, const uint32_t* __restrict__ wide_index, uint4* __restrict__ wide) {
+__global__ __launch_bounds__(256) void wide_nodes_kernel(const uint32_t* __restrict__ bvh4, uint32_t m, const uint32_t* __restrict__ wide_index, uint4* __restrict__ wide,
+                                                          uint32_t num_tris, uint32_t node_base16) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const uint32_t* r = bvh4 + 1 + (size_t)i * 8;
     if (r[7] & kLeaf) return;
     uint32_t box[12], ref[4];
     for (int s = 0; s < 4; ++s) {
-        box[3 * s] = box[3 * s + 1] = box[3 * s + 2] = 0u; ref[s] = kInvalidRef;
+        box[3 * s] = kEmptyBox0; box[3 * s + 1] = kEmptyBox1; box[3 * s + 2] = kEmptyBox2; ref[s] = kInvalidRef;   // the inverted box no ray enters (pt_device.h::slab_sel)
         const uint32_t c = r[3 + s];
         if (c == kInvalidRef || c >= m) continue;
         const uint32_t* cr = bvh4 + 1 + (size_t)c * 8;
         const uint32_t w0 = cr[0], w1 = cr[1], w2 = cr[2];
         if (box_degenerate(w0, w1, w2)) { ref[s] = kDegenerateRef; continue; }   // fetched by the reference, entered by no ray
         box[3 * s] = w0; box[3 * s + 1] = w1; box[3 * s + 2] = w2;
-        ref[s] = (cr[7] & kLeaf) ? (kLeaf | (cr[7] & 0x7fffffffu)) : wide_index[c];
+        const uint32_t tri = cr[7] & 0x7fffffffu;
+        ref[s] = (cr[7] & kLeaf) ? (kLeaf | (3u * (tri < num_tris ? tri : num_tris))) : node_base16 + 4u * wide_index[c];     // packed references (pt_host.h)
     }
     uint4* o = wide + (size_t)wide_index[i] * 4;
     o[0] = make_uint4(box[0], box[1], box[2], box[3]);
@@ -358,9 +360,9 @@ hipError_t launch_internal_scan(const BuildBuffers& B, const uint32_t* bvh4, uin
     return hipcub::DeviceScan::ExclusiveSum(B.temp, bytes, (const uint32_t*)B.subtree, B.ids, (int)num_nodes4, stream);
 }
 
-hipError_t launch_wide_nodes(const BuildBuffers& B, const uint32_t* bvh4, uint32_t num_nodes4, uint4* wide, hipStream_t stream) {
+hipError_t launch_wide_nodes(const BuildBuffers& B, const uint32_t* bvh4, uint32_t num_nodes4, uint4* wide, uint32_t num_tris, uint32_t node_base16, hipStream_t stream) {
     if (num_nodes4 == 0) return hipSuccess;
-    hipLaunchKernelGGL(wide_nodes_kernel, dim3(blocks(num_nodes4)), dim3(256), 0, stream, bvh4, num_nodes4, B.ids, wide);
+    hipLaunchKernelGGL(wide_nodes_kernel, dim3(blocks(num_nodes4)), dim3(256), 0, stream, bvh4, num_nodes4, B.ids, wide, num_tris, node_base16);
     return hipGetLastError();
 }
 

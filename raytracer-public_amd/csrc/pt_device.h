@@ -89,6 +89,35 @@ __device__ __forceinline__ bool slab(const Ray& r, uint32_t w0, uint32_t w1, uin
     return (tmax >= wmax(tmin, 0.0f)) & (tmin < best);
 }
 
+// The same test with the near / far bound of every axis picked by the sign of the ray's inverse direction instead of by
+// min / max: for inv >= 0, fl(mn - o) <= fl(mx - o) (rounding is monotone and mn <= mx) and the products keep that order, so
+// min(t1, t2) IS t1 and max(t1, t2) IS t2, bit for bit (for inv < 0 the other way round; equal values are the same number,
+// and a zero's sign never reaches a comparison result).  One v_perm_b32 per axis builds {near, far} as a pair of halves from
+// the packed box words -- 3 instructions in place of the 6 min / max.  The selectors are per ray (ray_selectors).
+// Empty and degenerate child slots hold the inverted box (+inf, -inf) (kEmptyBox*): near = +inf, far = -inf for either sign,
+// so the test fails by itself and the child references need no check.  (The min / max form above would accept such a box.)
+struct RaySel { uint32_t x, y, z; };
+__device__ __forceinline__ RaySel ray_selectors(F3 inv) {
+    RaySel s;
+    s.x = inv.x < 0.0f ? 0x01000706u : 0x07060100u;     // v_perm_b32(w1, w0): mn.x = bytes 0-1, mx.x = bytes 6-7
+    s.y = inv.y < 0.0f ? 0x03020504u : 0x05040302u;     // v_perm_b32(w2, w0): mn.y = bytes 2-3, mx.y = bytes 4-5
+    s.z = inv.z < 0.0f ? 0x01000706u : 0x07060100u;     // v_perm_b32(w2, w1): mn.z = bytes 0-1, mx.z = bytes 6-7
+    return s;
+}
+constexpr uint32_t kEmptyBox0 = 0x7C007C00u, kEmptyBox1 = 0xFC007C00u, kEmptyBox2 = 0xFC00FC00u;   // mn = +inf, mx = -inf (f16)
+// returns the hit mask of the wavefront's active lanes (the two comparisons are ballots of their own, combined on the scalar unit)
+__device__ __forceinline__ unsigned long long slab_sel(const F3& o, const F3& inv, const RaySel& sel, uint32_t w0, uint32_t w1, uint32_t w2, float best, float& tmin_out) {
+    const uint32_t bx = __builtin_amdgcn_perm(w1, w0, sel.x), by = __builtin_amdgcn_perm(w2, w0, sel.y), bz = __builtin_amdgcn_perm(w2, w1, sel.z);
+    const float nx = half_lo_minus(bx, o.x) * inv.x, ny = half_lo_minus(by, o.y) * inv.y, nz = half_lo_minus(bz, o.z) * inv.z;
+    const float fx = half_hi_minus(bx, o.x) * inv.x, fy = half_hi_minus(by, o.y) * inv.y, fz = half_hi_minus(bz, o.z) * inv.z;
+    const float tmin = wmax(wmax(nx, ny), nz);
+    const float tmax = wmin(wmin(fx, fy), fz);
+    tmin_out = tmin;
+    return __builtin_amdgcn_ballot_w64(tmax >= wmax(tmin, 0.0f)) & __builtin_amdgcn_ballot_w64(tmin < best);
+}
+// this lane's bit of a wavefront mask as a predicate (no instruction: the mask is used as the lane mask it is)
+__device__ __forceinline__ bool lane_of(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
 // ---- build-defined sampling; integer hash + fixed fmaf polynomials ----
 __device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 __device__ __forceinline__ uint32_t sample_key(uint32_t seed, uint32_t pixel, uint32_t sidx) {
@@ -168,6 +197,15 @@ __device__ __forceinline__ F3 light_dir() { return normalize3(f3(1.0f, 1.5f, 1.0
 __device__ __forceinline__ F3 tri_normal(const RenderArgs& A, uint32_t ti) {
     const float4 c = A.tris[(size_t)ti * 3 + 2];
     return f3(c.y, c.z, c.w);
+}
+// Packed references (pt_host.h): a record's position in the scene arena in 16-byte units, leaf flag in bit 31 -- `ref << 4` is
+// the byte offset of the record whichever kind it is (the shift drops the flag).
+__device__ __forceinline__ const uint4* arena_record(const RenderArgs& A, uint32_t ref) {
+    return (const uint4*)((const char*)A.scene + (ref << 4));
+}
+__device__ __forceinline__ F3 tri_normal_ref(const RenderArgs& A, uint32_t leaf_ref) {
+    const uint4 c = arena_record(A, leaf_ref)[2];
+    return f3(__uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w));
 }
 
 

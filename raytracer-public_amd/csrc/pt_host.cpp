@@ -232,7 +232,7 @@ static inline bool box_degenerate(uint32_t w0, uint32_t w1, uint32_t w2) {
            half_to_float(w1 & 0xffffu) > half_to_float(w2 >> 16);
 }
 
-bool build_wide_bvh(const uint32_t* bvh4, uint64_t words, WideBvh& out, std::string& err) {
+bool build_wide_bvh(const uint32_t* bvh4, uint64_t words, uint32_t num_tris, uint32_t node_base16, WideBvh& out, std::string& err) {
     out = WideBvh();
     if (words < 1) { err = "empty BVH buffer"; return false; }
     const uint32_t m = bvh4[0];
@@ -264,20 +264,20 @@ bool build_wide_bvh(const uint32_t* bvh4, uint64_t words, WideBvh& out, std::str
     const uint32_t* r0 = rec(0);
     out.root_box[0] = r0[0]; out.root_box[1] = r0[1]; out.root_box[2] = r0[2];
     out.root_degenerate = box_degenerate(r0[0], r0[1], r0[2]);
-    out.root_ref = (r0[7] & kLeafFlag) ? (kLeafFlag | (r0[7] & 0x7fffffffu)) : 0u;
+    out.root_ref = (r0[7] & kLeafFlag) ? packed_leaf_ref(r0[7] & 0x7fffffffu, num_tris) : node_base16;
     out.nodes.resize(order.size());
     for (size_t w = 0; w < order.size(); ++w) {
         const uint32_t* r = rec(order[w]);
         WideNode& wn = out.nodes[w];
         for (int s = 0; s < 4; ++s) {
             const uint32_t c = r[3 + s];
-            wn.box[s][0] = wn.box[s][1] = wn.box[s][2] = 0u;
+            wn.box[s][0] = kEmptyBox0; wn.box[s][1] = kEmptyBox1; wn.box[s][2] = kEmptyBox2;   // the inverted box (+inf, -inf) no ray enters
             wn.ref[s] = kInvalid;
             if (c == kInvalid || c >= m) continue;
             const uint32_t* cr = rec(c);
             if (box_degenerate(cr[0], cr[1], cr[2])) { wn.ref[s] = kDegenerate; continue; }   // renderer.wgsl:291: fetched, then skipped
             wn.box[s][0] = cr[0]; wn.box[s][1] = cr[1]; wn.box[s][2] = cr[2];
-            wn.ref[s] = (cr[7] & kLeafFlag) ? (kLeafFlag | (cr[7] & 0x7fffffffu)) : wide_index[c];
+            wn.ref[s] = (cr[7] & kLeafFlag) ? packed_leaf_ref(cr[7] & 0x7fffffffu, num_tris) : node_base16 + 4u * wide_index[c];
         }
     }
     return true;

@@ -10,6 +10,7 @@ constexpr uint32_t kNode2Stride = 6;            // BVHBuilder.wgsl:5
 constexpr uint32_t kNode4Stride = 8;            // renderer.wgsl:10
 constexpr uint32_t kLeafFlag    = 0x80000000u;  // renderer.wgsl:11
 constexpr uint32_t kInvalid     = 0xFFFFFFFFu;  // renderer.wgsl:12
+constexpr uint32_t kEmptyBox0 = 0x7C007C00u, kEmptyBox1 = 0xFC007C00u, kEmptyBox2 = 0xFC00FC00u;   // wide layout: box words of an empty or degenerate child slot, mn = +inf, mx = -inf (f16)
 constexpr uint32_t kDegenerate  = 0xFFFFFFFEu;  // wide layout only: a child the reference fetches and then rejects for every ray (renderer.wgsl:291)
 
 // ---- f16 codec -------------------------------------------------------------------
@@ -28,10 +29,17 @@ bool promote_to_bvh4_wide(const uint32_t* bvh2, uint64_t words, std::vector<uint
 // (3 words each, reference packing) followed by four child references.
 struct WideNode {
     uint32_t box[4][3];
-    uint32_t ref[4];   // kInvalid = empty slot; kDegenerate = examined, never entered; kLeafFlag|tri = leaf; else index of a WideNode
+    uint32_t ref[4];   // kInvalid = empty slot; kDegenerate = examined, never entered; else a packed reference (below)
 };
 static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 
+// Packed references: the traversal gathers triangle records (48 B) and wide nodes (64 B) from ONE arena, so a child reference
+// is the record's position in it in 16-byte units -- `ref << 4` is the byte offset, and the shift drops the leaf flag:
+//   leaf        kLeafFlag | 3 * tri                 (triangle record `tri` at byte 48 * tri)
+//   wide node   node_base16 + 4 * index             (node `index` at byte 16 * node_base16 + 64 * index)
+// A leaf whose triangle index is >= num_tris (the reference enters such a leaf and tests nothing, renderer.wgsl:262) points at
+// the all-zero record behind the last triangle (index num_tris: never hit, |det| < eps).
+inline uint32_t packed_leaf_ref(uint32_t tri, uint32_t num_tris) { return kLeafFlag | (3u * (tri < num_tris ? tri : num_tris)); }
 struct WideBvh {
     std::vector<WideNode> nodes;
     uint32_t root_ref = kInvalid;      // same encoding as WideNode::ref; kInvalid = empty BVH
@@ -44,7 +52,7 @@ struct WideBvh {
 // fetching them (INVALID, index >= numNodes: renderer.wgsl:288) become empty slots; a child with a
 // degenerate box (fetched, then rejected: renderer.wgsl:289-291) becomes a kDegenerate slot, which
 // no ray enters but which counts as an examined record, exactly as in the reference.
-bool build_wide_bvh(const uint32_t* bvh4, uint64_t words, WideBvh& out, std::string& err);
+bool build_wide_bvh(const uint32_t* bvh4, uint64_t words, uint32_t num_tris, uint32_t node_base16, WideBvh& out, std::string& err);
 
 // 48-byte triangle record: v0, e1 = v1-v0, e2 = v2-v0, n = normalize(cross(e1,e2)) -- the same
 // f32 operations renderer.wgsl:179-180,269 performs per visit, done once at upload.

@@ -55,7 +55,8 @@ struct RenderArgs {
     // device scene, MI355X layouts
     const uint4*  nodes;        // WideNode[]: 64 B per internal BVH4 node, read as 4 x dwordx4
     const float4* tris;         // TriRecord[]: 48 B per triangle, read as 3 x dwordx4
-    const uint4*  scene;        // the arena both arrays live in: triangle record t at byte 48 t, wide node i at byte node_off + 64 i
+    const uint4*  scene;        // the arena both arrays live in: triangle record t at byte 48 t, wide node i at byte node_off + 64 i;
+                                // child references are positions in it in 16-byte units (packed references, pt_host.h)
     uint32_t      node_off;
     // device scene, reference layouts (literal packet kernel, LBVH build, readback)
     const uint32_t* bvh4_ref;   // u32[1 + 8*M]   renderer.wgsl:91-111
@@ -138,7 +139,7 @@ hipError_t launch_morton_sort(const BuildBuffers& B, const float* tris9, uint32_
 hipError_t collapse_on_device(const BuildBuffers& B, const uint32_t* bvh2, uint32_t num_tris, uint32_t* bvh4, uint32_t* num_nodes4, hipStream_t stream);
 // B.subtree[i] = 1 for internal node id i, B.ids = its exclusive prefix sum (the wide-node index)
 hipError_t launch_internal_scan(const BuildBuffers& B, const uint32_t* bvh4, uint32_t num_nodes4, hipStream_t stream);
-hipError_t launch_wide_nodes(const BuildBuffers& B, const uint32_t* bvh4, uint32_t num_nodes4, uint4* wide, hipStream_t stream);
+hipError_t launch_wide_nodes(const BuildBuffers& B, const uint32_t* bvh4, uint32_t num_nodes4, uint4* wide, uint32_t num_tris, uint32_t node_base16, hipStream_t stream);
 hipError_t launch_deinterleave(const float4* gathered, uint64_t stride_px, float4* full, uint32_t width, uint32_t height,
                                uint32_t count, hipStream_t stream);
 hipError_t launch_rgba8(const float4* src, uint32_t* dst, uint32_t n, hipStream_t stream);

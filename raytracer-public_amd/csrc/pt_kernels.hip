@@ -37,9 +37,10 @@ __device__ __forceinline__ bool traverse(const RenderArgs& A, const Ray& r, floa
     for (;;) {
         bool need_pop = false;
         if (cur & kLeaf) {
-            const uint32_t ti = cur & 0x7fffffffu;
-            if (ti < A.num_tris) {
-                const float4* tp = A.tris + (size_t)ti * 3;
+            const uint32_t ti3 = cur & 0x7fffffffu;               // packed reference: 3 * triangle index (16-byte units of 48 B records)
+            if (ti3 < 3u * A.num_tris) {                          // renderer.wgsl:262 (an out-of-range leaf points at record num_tris)
+                const uint32_t ti = __umulhi(ti3, 0xAAAAAAABu) >> 1;
+                const float4* tp = (const float4*)arena_record(A, cur);
                 const float4 a = tp[0], b = tp[1], c = tp[2];
                 if (STATS) cnt.tris += 1;
                 const F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
@@ -64,7 +65,7 @@ __device__ __forceinline__ bool traverse(const RenderArgs& A, const Ray& r, floa
             }
             need_pop = true;
         } else {
-            const uint4* np = A.nodes + (size_t)cur * 4;
+            const uint4* np = arena_record(A, cur);
             const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             float t0, t1, t2, t3;
             const bool h0 = (n3.x < kDegenerateRef) && slab(r, n0.x, n0.y, n0.z, best_t, t0);

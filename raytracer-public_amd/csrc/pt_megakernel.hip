@@ -30,6 +30,7 @@ constexpr uint32_t kPhaseIdle = 0, kPhaseTrav = 1, kPhaseDone = 2, kPhaseParked 
 struct Lane {
     // ray
     F3 o, d, inv;
+    RaySel sel;           // near / far picks of the slab test, from the signs of inv (pt_device.h::slab_sel)
     float best_t; uint32_t best_tri;
     uint32_t cur; int sp;
     // path
@@ -40,6 +41,16 @@ struct Lane {
 };
 
 constexpr uint32_t kShadowBit = 1u << 16, kContBit = 1u << 17;
+
+// x + (this lane's bit of a wavefront mask): one v_addc_co_u32 with the mask as the carry input
+// (s_nop 1: two wait states between a vector compare that wrote the mask and its use as a carry input, whatever was scheduled between)
+__device__ __forceinline__ void add_lane_bits3(int x, unsigned long long m0, unsigned long long m1, unsigned long long m2, int& x1, int& x2, int& x3) {
+    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, vcc, 0, %3, %4\n\tv_addc_co_u32_e64 %1, vcc, 0, %0, %5\n\tv_addc_co_u32_e64 %2, vcc, 0, %1, %6"
+        : "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(x), "s"(m0), "s"(m1), "s"(m2) : "vcc");
+}
+// v_min_f32 / v_min3_f32 on values that are never NaN (no canonicalisation of the inputs)
+__device__ __forceinline__ float min_f32(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float min3_f32(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // CONT = false: pass 0, items are pixel-samples generated from the permuted batch queue.
 // CONT = true : continuation pass, items are path records flushed by the previous pass.
@@ -80,7 +91,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
     Lane S;
     uint32_t phase = kPhaseIdle;
     S.sp = 0; S.cur = 0; S.best_t = kInfT; S.best_tri = kInvalidRef; S.bounce = 0; S.key = 0; S.item = 0;
-    S.o = S.d = S.inv = S.T = S.rad = S.d_next = S.contrib = f3(0, 0, 0);
+    S.o = S.d = S.inv = S.T = S.rad = S.d_next = S.contrib = f3(0, 0, 0); S.sel = ray_selectors(S.inv);
     uint32_t c_nodes = 0, c_tris = 0, c_drops = 0, c_maxstack = 0, c_closest = 0, c_shadow = 0, c_samples = 0;
 
     // ---- helpers as lambdas (all inlined) -------------------------------------------------
@@ -102,6 +113,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
         float troot;
         if (!slab(r, A.root_box[0], A.root_box[1], A.root_box[2], kInfT, troot)) return false;
         S.cur = A.root_ref;
+        S.sel = ray_selectors(S.inv);
         return true;
     };
 
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                         S.rad = S.rad + S.T * ((bounce == 0u) ? kBgPrimary : kSkyAmbient);
                         finish = true;
                     } else {
-                        const F3 n = tri_normal(A, S.best_tri);
+                        const F3 n = tri_normal_ref(A, S.best_tri);
                         const F3 hp = S.o + S.d * S.best_t;
                         const F3 nf = (dot3(n, S.d) < 0.0f) ? n : f3(-n.x, -n.y, -n.z);
                         const F3 so = hp + nf * kEpsOrigin;
@@ -270,112 +282,110 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
         }
         // ------------------------------------------------------------------ one traversal step
         if (STATS) { cy_mark = __builtin_amdgcn_s_memtime(); ++n_iter; lanes_sum += __popcll(m_trav); leaf_lanes += __popcll(__ballot(phase == kPhaseTrav && (S.cur & kLeaf))); }
-        // Leaf postponement: the triangle test is ~100 instructions that only ~15 % of the traversing lanes
-        // need in any one step.  Lanes that reach a leaf wait until leaf_threshold of them are there (or no
-        // lane can make progress on nodes); each lane's own visit sequence is unchanged.
-        const unsigned long long m_leaf = __ballot(phase == kPhaseTrav && (S.cur & kLeaf) != 0u);
-        const bool do_leaf = (uint32_t)__popcll(m_leaf) >= A.leaf_threshold || m_leaf == m_trav;
-        if (phase == kPhaseTrav && (do_leaf || (S.cur & kLeaf) == 0u)) {
+        if (phase == kPhaseTrav) {
             bool need_pop = false;
-            Ray r; r.o = S.o; r.d = S.d; r.inv = S.inv;
-            // Unified fetch: a lane is either at an internal node (64 B record) or at a leaf (48 B
-            // triangle record).  Both kinds are fetched by the same four dwordx4 loads BEFORE the
-            // node/leaf branch, so a wavefront with mixed lanes pays one memory latency per step, not
-            // two.  (A leaf lane over-reads 16 B into the next record; the buffers are padded.)
+            // Unified fetch: a lane is either at an internal node (64 B record) or at a leaf (48 B triangle record).  Both kinds
+            // live in one arena and a reference is the record's position in it (packed references, pt_host.h), so the same four
+            // dwordx4 loads at `cur << 4` fetch either kind BEFORE the node/leaf branch: a wavefront with mixed lanes pays one
+            // memory latency per step, not two.  (A leaf lane over-reads 16 B into the next record; the arena is padded.)
             const bool at_leaf = (S.cur & kLeaf) != 0u;
-            const uint32_t ti = S.cur & 0x7fffffffu;
-            const bool tri_ok = ti < A.num_tris;
-            const uint4* rec = at_leaf ? (const uint4*)(A.tris + (size_t)(tri_ok ? ti : 0u) * 3) : (A.nodes + (size_t)S.cur * 4);
+            const uint4* rec = arena_record(A, S.cur);
             uint4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
             // keep the four loads here: without this the compiler sinks them into the two branches again
-            asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z), "+v"(n1.w),
-                              "+v"(n2.x), "+v"(n2.y), "+v"(n2.z), "+v"(n2.w), "+v"(n3.x), "+v"(n3.y), "+v"(n3.z), "+v"(n3.w));
+            asm volatile("" : "+v"(n0.x), "+v"(n1.x), "+v"(n2.x), "+v"(n3.x));
             if (at_leaf) {
-                if (tri_ok) {
-                    const float4 a = make_float4(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z), __uint_as_float(n0.w));
-                    const float4 b = make_float4(__uint_as_float(n1.x), __uint_as_float(n1.y), __uint_as_float(n1.z), __uint_as_float(n1.w));
-                    const float4 c = make_float4(__uint_as_float(n2.x), __uint_as_float(n2.y), __uint_as_float(n2.z), __uint_as_float(n2.w));
-                    if (STATS) ++c_tris;
-                    const F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
-                    // branch-free Moller-Trumbore (renderer.wgsl:185-205): same operations and comparisons,
-                    // rejections combined at the end, so the 48 B record is fetched in one go
-                    const F3 pv = cross3(r.d, e2);
-                    const float det = dot3(e1, pv);
-                    const bool ok_det = !(fabsf(det) < kTriEps);
-                    const float inv_det = 1.0f / det;
-                    const F3 sv = r.o - v0;
-                    const float u = inv_det * dot3(sv, pv);
-                    const bool ok_u = !((u < 0.0f) | (u > 1.0f));
-                    const F3 q = cross3(sv, e1);
-                    const float v = inv_det * dot3(r.d, q);
-                    const bool ok_v = !((v < 0.0f) | ((u + v) > 1.0f));
-                    const float t = inv_det * dot3(e2, q);
-                    if (ok_det & ok_u & ok_v & (t > kTriEps) & (t < S.best_t)) {
-                        S.best_t = t; S.best_tri = ti;
-                        if (S.bounce & kShadowBit) phase = kPhaseDone;   // any-hit: first accepted hit ends the ray
-                    }
+                const float4 a = make_float4(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z), __uint_as_float(n0.w));
+                const float4 b = make_float4(__uint_as_float(n1.x), __uint_as_float(n1.y), __uint_as_float(n1.z), __uint_as_float(n1.w));
+                const float4 c = make_float4(__uint_as_float(n2.x), __uint_as_float(n2.y), __uint_as_float(n2.z), __uint_as_float(n2.w));
+                // a leaf whose triangle index is out of range points at the all-zero record behind the last triangle: the test
+                // below fails on |det| < eps, as if it had not been made (renderer.wgsl:262); only the counter has to know
+                if (STATS) { if ((S.cur & 0x7fffffffu) < 3u * A.num_tris) ++c_tris; }
+                const F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
+                // branch-free Moller-Trumbore (renderer.wgsl:185-205): same operations and comparisons,
+                // rejections combined at the end, so the 48 B record is fetched in one go
+                const F3 pv = cross3(S.d, e2);
+                const float det = dot3(e1, pv);
+                const bool ok_det = !(fabsf(det) < kTriEps);
+                const float inv_det = 1.0f / det;
+                const F3 sv = S.o - v0;
+                const float u = inv_det * dot3(sv, pv);
+                const bool ok_u = !((u < 0.0f) | (u > 1.0f));
+                const F3 q = cross3(sv, e1);
+                const float v = inv_det * dot3(S.d, q);
+                const bool ok_v = !((v < 0.0f) | ((u + v) > 1.0f));
+                const float t = inv_det * dot3(e2, q);
+                if (ok_det & ok_u & ok_v & (t > kTriEps) & (t < S.best_t)) {
+                    S.best_t = t; S.best_tri = S.cur;
+                    if (S.bounce & kShadowBit) phase = kPhaseDone;   // any-hit: first accepted hit ends the ray
                 }
                 need_pop = true;
             } else {
                 float t0, t1, t2, t3;
-                // all four slab tests are evaluated unconditionally (empty slots hold zero boxes and are
-                // masked by their ref): one 64 B fetch, no per-child branches or dependent waits
-                const bool s0 = slab(r, n0.x, n0.y, n0.z, S.best_t, t0);
-                const bool s1 = slab(r, n0.w, n1.x, n1.y, S.best_t, t1);
-                const bool s2 = slab(r, n1.z, n1.w, n2.x, S.best_t, t2);
-                const bool s3 = slab(r, n2.y, n2.z, n2.w, S.best_t, t3);
-                // enterable slots: neither empty (kInvalidRef) nor a degenerate child (kDegenerateRef: counted below, never entered)
-                const bool h0 = s0 & (n3.x < kDegenerateRef), h1 = s1 & (n3.y < kDegenerateRef);
-                const bool h2 = s2 & (n3.z < kDegenerateRef), h3 = s3 & (n3.w < kDegenerateRef);
+                // all four slab tests are evaluated unconditionally: one 64 B fetch, no per-child branches or dependent
+                // waits.  Empty slots and degenerate children (kDegenerateRef: counted below, never entered) hold the inverted
+                // box, which slab_sel rejects by itself
+                const unsigned long long H0 = slab_sel(S.o, S.inv, S.sel, n0.x, n0.y, n0.z, S.best_t, t0);
+                const unsigned long long H1 = slab_sel(S.o, S.inv, S.sel, n0.w, n1.x, n1.y, S.best_t, t1);
+                const unsigned long long H2 = slab_sel(S.o, S.inv, S.sel, n1.z, n1.w, n2.x, S.best_t, t2);
+                const unsigned long long H3 = slab_sel(S.o, S.inv, S.sel, n2.y, n2.z, n2.w, S.best_t, t3);
                 if (STATS) c_nodes += (n3.x != kInvalidRef) + (n3.y != kInvalidRef) + (n3.z != kInvalidRef) + (n3.w != kInvalidRef);
                 // Branch-free form of renderer.wgsl:314-342 for one lane.  Hit children keep slot order;
                 // the nearest (first minimum of tmin) is entered next and trades places with the first
                 // hit, so the stacked entry for slot s is the first hit's when s is the nearest slot, the
                 // slot's own child otherwise -- and a slot is stacked iff it is hit and is not the first hit.
+                // All predicates are wavefront masks: their logic runs on the scalar unit, the vector unit only selects.
                 const float kBig = 3.0e38f;
-                const float e0 = h0 ? t0 : kBig, e1 = h1 ? t1 : kBig, e2 = h2 ? t2 : kBig, e3 = h3 ? t3 : kBig;
-                const float tn = wmin(wmin(e0, e1), wmin(e2, e3));
-                const bool any = h0 | h1 | h2 | h3;
-                // nearest slot = first slot (in slot order) whose tmin equals the minimum
-                const bool m0 = h0 & (e0 == tn), m1 = h1 & (e1 == tn) & !m0, m2 = h2 & (e2 == tn) & !(m0 | m1);
-                const bool m3 = !(m0 | m1 | m2);
-                const uint32_t rn = m0 ? n3.x : m1 ? n3.y : m2 ? n3.z : n3.w;
-                const uint32_t rf = h0 ? n3.x : h1 ? n3.y : h2 ? n3.z : n3.w;      // first hit
-                const float tf = h0 ? t0 : h1 ? t1 : h2 ? t2 : t3;
-                if (!any) need_pop = true;
-                else {
-                    const bool p3 = h3 & (h0 | h1 | h2), p2 = h2 & (h0 | h1), p1 = h1 & h0;
-                    const unsigned long long en = ((unsigned long long)__float_as_uint(tf) << 32) | rf;
-                    const unsigned long long w3 = m3 ? en : (((unsigned long long)__float_as_uint(t3) << 32) | n3.w);
-                    const unsigned long long w2 = m2 ? en : (((unsigned long long)__float_as_uint(t2) << 32) | n3.z);
-                    const unsigned long long w1 = m1 ? en : (((unsigned long long)__float_as_uint(t1) << 32) | n3.y);
+                const float e0 = lane_of(H0) ? t0 : kBig, e1 = lane_of(H1) ? t1 : kBig, e2 = lane_of(H2) ? t2 : kBig, e3 = lane_of(H3) ? t3 : kBig;
+                const float tn = min_f32(min3_f32(e0, e1, e2), e3);
+                // nearest slot = first slot (in slot order) whose tmin equals the minimum (with any hit, tn < kBig, so a slot that
+                // equals it is a hit slot)
+                const unsigned long long Q0 = __builtin_amdgcn_ballot_w64(e0 == tn), Q1 = __builtin_amdgcn_ballot_w64(e1 == tn), Q2 = __builtin_amdgcn_ballot_w64(e2 == tn);
+                const unsigned long long M1 = Q1 & ~Q0, M2 = Q2 & ~(Q0 | Q1), M3 = ~(Q0 | Q1 | Q2);
+                const uint32_t rn = lane_of(Q0) ? n3.x : lane_of(M1) ? n3.y : lane_of(M2) ? n3.z : n3.w;
+                if (lane_of(H0 | H1 | H2 | H3)) {
+                    // slot s (1..3) is stacked iff it is hit and an earlier slot is hit too (so it is not the first hit); the first hit
+                    // among the slots before s is then what the nearest slot hands over
+                    const unsigned long long P3 = H3 & (H0 | H1 | H2), P2 = H2 & (H0 | H1), P1 = H1 & H0;
+                    const float tf01 = lane_of(H0) ? t0 : t1; const uint32_t rf01 = lane_of(H0) ? n3.x : n3.y;                     // first hit of slots 0..1 (when there is one)
+                    const float tf012 = lane_of(H0 | H1) ? tf01 : t2; const uint32_t rf012 = lane_of(H0 | H1) ? rf01 : n3.z;     // first hit of slots 0..2
+                    const unsigned long long w3 = ((unsigned long long)__float_as_uint(lane_of(M3) ? tf012 : t3) << 32) | (lane_of(M3) ? rf012 : n3.w);
+                    const unsigned long long w2 = ((unsigned long long)__float_as_uint(lane_of(M2) ? tf01 : t2) << 32) | (lane_of(M2) ? rf01 : n3.z);
+                    const unsigned long long w1 = ((unsigned long long)__float_as_uint(lane_of(M1) ? t0 : t1) << 32) | (lane_of(M1) ? n3.x : n3.y);
                     if (__builtin_expect(S.sp + 3 <= kShort, 1)) {
                         // fast path: three unconditional LDS stores far -> near; an entry that is not
                         // stacked is simply overwritten by the next one (the slot index does not advance)
-                        int sp = S.sp;
-                        stk[sp * 64] = w3; sp += p3 ? 1 : 0;
-                        stk[sp * 64] = w2; sp += p2 ? 1 : 0;
-                        stk[sp * 64] = w1; sp += p1 ? 1 : 0;
+                        int sp1, sp2, sp;
+                        add_lane_bits3(S.sp, P3, P2, P1, sp1, sp2, sp);
+                        stk[S.sp * 64] = w3; stk[sp1 * 64] = w2; stk[sp2 * 64] = w1;
                         if (STATS) { const int k = sp - S.sp; push_ops += k; for (int j = S.sp; j < sp; ++j) { if (j >= 8) ++push8_ops; if (j >= 12) ++push12_ops; } }
                         S.sp = sp;
+                        if (STATS) { const uint32_t depth = (uint32_t)S.sp + 1u; if (depth > c_maxstack) c_maxstack = depth; }   // entries incl. the nearest child
+                        S.cur = rn;
                     } else {
-                        if (p3) push((uint32_t)w3, __uint_as_float((uint32_t)(w3 >> 32)));
-                        if (p2) push((uint32_t)w2, __uint_as_float((uint32_t)(w2 >> 32)));
-                        if (p1) push((uint32_t)w1, __uint_as_float((uint32_t)(w1 >> 32)));
+                        if (lane_of(P3)) push((uint32_t)w3, __uint_as_float((uint32_t)(w3 >> 32)));
+                        if (lane_of(P2)) push((uint32_t)w2, __uint_as_float((uint32_t)(w2 >> 32)));
+                        if (lane_of(P1)) push((uint32_t)w1, __uint_as_float((uint32_t)(w1 >> 32)));
+                        if (STATS) { const uint32_t depth = (uint32_t)S.sp + (S.sp < kStackMax ? 1u : 0u); if (depth > c_maxstack) c_maxstack = depth; }   // entries incl. the nearest child, if its push fitted
+                        if (S.sp < kStackMax) S.cur = rn;
+                        else { need_pop = true; if (STATS) ++c_drops; }
                     }
-                    if (STATS) { const uint32_t depth = (uint32_t)S.sp + (S.sp < kStackMax ? 1u : 0u); if (depth > c_maxstack) c_maxstack = depth; }   // entries incl. the nearest child, if its push fitted
-                    if (S.sp < kStackMax) S.cur = rn;
-                    else { need_pop = true; if (STATS) ++c_drops; }
-                }
+                } else need_pop = true;
             }
             if (need_pop && phase == kPhaseTrav) {
                 bool found = false;
-                while (S.sp > 0) {
+                // deep entries (index >= kShort) live in the spill area: rare
+                while (__builtin_expect(S.sp > kShort, 0)) {
                     --S.sp;
-                    // the LDS slot is read unconditionally (index clamped); deep entries override it from the spill area
-                    unsigned long long e = stk[(S.sp < kShort ? S.sp : kShort - 1) * 64];
-                    if (__builtin_expect(S.sp >= kShort, 0)) e = *(volatile unsigned long long*)&spill[(size_t)(S.sp - kShort) * spill_stride];   // volatile: keeps the rare global read out of the LDS fast path
+                    const unsigned long long e = *(volatile unsigned long long*)&spill[(size_t)(S.sp - kShort) * spill_stride];
                     if (__uint_as_float((uint32_t)(e >> 32)) < S.best_t) { S.cur = (uint32_t)e; found = true; break; }
+                }
+                if (!found) {
+                    // entries whose box the ray no longer reaches (tmin >= best) are skipped: a lean loop, one LDS read per entry
+                    while (S.sp > 0) {
+                        --S.sp;
+                        const unsigned long long e = stk[S.sp * 64];
+                        if (__uint_as_float((uint32_t)(e >> 32)) < S.best_t) { S.cur = (uint32_t)e; found = true; break; }
+                    }
                 }
                 // a camera ray that found nothing leaves its sample at the primed miss value (0 + 1 * 0.01, renderer.wgsl:410): no shade pass, the lane is free
                 if (!found) phase = (S.bounce == 0u && S.best_tri == kInvalidRef) ? kPhaseIdle : kPhaseDone;
