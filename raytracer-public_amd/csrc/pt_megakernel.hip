@@ -280,8 +280,9 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
             if (m_done == 0ull && queue_empty) break;    // donated paths are picked up by the continuation pass
             continue;
         }
-        // ------------------------------------------------------------------ one traversal step
-        if (STATS) { cy_mark = __builtin_amdgcn_s_memtime(); ++n_iter; lanes_sum += __popcll(m_trav); leaf_lanes += __popcll(__ballot(phase == kPhaseTrav && (S.cur & kLeaf))); }
+        // ------------------------------------------------------------------ traversal steps, until one of the passes above is due again
+        for (;;) {
+        if (STATS) { cy_mark = __builtin_amdgcn_s_memtime(); ++n_iter; lanes_sum += __popcll(__ballot(phase == kPhaseTrav)); leaf_lanes += __popcll(__ballot(phase == kPhaseTrav && (S.cur & kLeaf))); }
         if (phase == kPhaseTrav) {
             bool need_pop = false;
             // Unified fetch: a lane is either at an internal node (64 B record) or at a leaf (48 B triangle record).  Both kinds
@@ -392,6 +393,12 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
             }
         }
         if (STATS) { const unsigned long long dt = __builtin_amdgcn_s_memtime() - cy_mark; cy_step += dt; if (!queue_empty) cy_step_q += dt; }
+        // the conditions of the shade / donate / refill passes, exactly as they are tested at the top of the outer loop
+        const unsigned long long now_trav = __ballot(phase == kPhaseTrav);
+        if (now_trav == 0ull) break;
+        if ((uint32_t)__popcll(__ballot(phase == kPhaseDone)) >= A.shade_threshold) break;
+        if (!queue_empty && (uint32_t)__popcll(__ballot(phase == kPhaseIdle)) >= A.fill_threshold) break;
+        }
     }
     if (STATS) {
         if (!CONT && A.wave_times && lane == 0) {
