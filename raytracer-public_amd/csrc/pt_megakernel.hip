@@ -24,6 +24,12 @@
 
 namespace ptk {
 
+// A wavefront that has found the queue dry only finishes the paths it holds: from then on it is on the critical path of its launch
+// (the longest chain of dependent steps ends it) while the wavefronts of the next launch next to it are throughput work.
+#ifndef PT_TAIL_PRIORITY
+#define PT_TAIL_PRIORITY 3
+#endif
+#define PT_TAIL_PRIO do { if (PT_TAIL_PRIORITY) __builtin_amdgcn_s_setprio(PT_TAIL_PRIORITY); } while (0)
 constexpr int kShort = PT_SHORT_STACK;    // LDS entries per lane
 constexpr uint32_t kPhaseIdle = 0, kPhaseTrav = 1, kPhaseDone = 2, kPhaseParked = 3;   // parked: waiting at a closest-ray boundary to be donated
 
@@ -117,12 +123,21 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
         return true;
     };
 
+    // Lanes whose ray has ended wait for a shade pass until shade_threshold of them are there: the pass costs a wavefront as much
+    // as 1.5 traversal steps whatever the number of lanes in it.  Once the queue is dry a wavefront thins out, and a lane that
+    // waited for a crowd would wait for the other lanes' whole rays -- the paths of a wavefront would run one after the other,
+    // and it is the longest chain of dependent steps that ends a launch.  So then a quarter of the live lanes is enough.
+    auto shade_due = [&](unsigned long long m_live) -> uint32_t {
+        if (!queue_empty) return A.shade_threshold;
+        const uint32_t q = (uint32_t)__popcll(m_live) >> 2;
+        return q < 1u ? 1u : (q < A.shade_threshold ? q : A.shade_threshold);
+    };
     for (;;) {
         // ------------------------------------------------------------------ shade DONE lanes
         {
             const unsigned long long m_done = __ballot(phase == kPhaseDone);
             const unsigned long long m_trav = __ballot(phase == kPhaseTrav);
-            if (m_done != 0ull && ((uint32_t)__popcll(m_done) >= A.shade_threshold || m_trav == 0ull)) {
+            if (m_done != 0ull && ((uint32_t)__popcll(m_done) >= shade_due(m_trav | m_done) || m_trav == 0ull)) {
                 if (STATS) { ++n_shade; cy_mark = __builtin_amdgcn_s_memtime(); }
                 // sparse wavefront and nothing left to regenerate from: hand the surviving paths to the
                 // next pass (at a closest-ray boundary) instead of finishing them at low lane utilisation
@@ -229,13 +244,13 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                             if (lane == 0) start = atomicAdd(A.queue + 8 + qi, chunk_items);
                             start = __builtin_amdgcn_readfirstlane(start);
                             if (q_begin < q_end && start < q_end - q_begin) { chunk_next = q_begin + start; chunk_end = min(chunk_next + chunk_items, q_end); break; }
-                            if (++xcd_hop == 8u) { queue_empty = true; if (STATS) { t_qempty = wall_clock64(); n_iter_q = n_iter; lanes_sum_q = lanes_sum; } break; }
+                            if (++xcd_hop == 8u) { queue_empty = true; PT_TAIL_PRIO; if (STATS) { t_qempty = wall_clock64(); n_iter_q = n_iter; lanes_sum_q = lanes_sum; } break; }
                         }
                     } else {
                     uint32_t start = 0;
                     if (lane == 0) start = atomicAdd(A.queue, chunk_items);
                     start = __builtin_amdgcn_readfirstlane(start);
-                    if (start >= total_items) { queue_empty = true; if (STATS) { t_qempty = wall_clock64(); n_iter_q = n_iter; lanes_sum_q = lanes_sum; } }
+                    if (start >= total_items) { queue_empty = true; PT_TAIL_PRIO; if (STATS) { t_qempty = wall_clock64(); n_iter_q = n_iter; lanes_sum_q = lanes_sum; } }
                     else { chunk_next = start; chunk_end = min(start + chunk_items, total_items); }
                     }
                 }
@@ -380,13 +395,14 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                     const unsigned long long e = *(volatile unsigned long long*)&spill[(size_t)(S.sp - kShort) * spill_stride];
                     if (__uint_as_float((uint32_t)(e >> 32)) < S.best_t) { S.cur = (uint32_t)e; found = true; break; }
                 }
-                if (!found) {
-                    // entries whose box the ray no longer reaches (tmin >= best) are skipped: a lean loop, one LDS read per entry
-                    while (S.sp > 0) {
-                        --S.sp;
-                        const unsigned long long e = stk[S.sp * 64];
-                        if (__uint_as_float((uint32_t)(e >> 32)) < S.best_t) { S.cur = (uint32_t)e; found = true; break; }
-                    }
+                if (!found && S.sp > 0) {
+                    // entries whose box the ray no longer reaches (tmin >= best) are skipped: a lean loop that walks down the lane's
+                    // column of the LDS stack -- per entry one address step, one read, two compares
+                    int i = S.sp;
+                    unsigned long long e;
+                    do { --i; e = stk[i * 64]; found = __uint_as_float((uint32_t)(e >> 32)) < S.best_t; } while (!found && i > 0);
+                    S.sp = i;
+                    if (found) S.cur = (uint32_t)e;
                 }
                 // a camera ray that found nothing leaves its sample at the primed miss value (0 + 1 * 0.01, renderer.wgsl:410): no shade pass, the lane is free
                 if (!found) phase = (S.bounce == 0u && S.best_tri == kInvalidRef) ? kPhaseIdle : kPhaseDone;
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
         // the conditions of the shade / donate / refill passes, exactly as they are tested at the top of the outer loop
         const unsigned long long now_trav = __ballot(phase == kPhaseTrav);
         if (now_trav == 0ull) break;
-        if ((uint32_t)__popcll(__ballot(phase == kPhaseDone)) >= A.shade_threshold) break;
+        if ((uint32_t)__popcll(__ballot(phase == kPhaseDone)) >= shade_due(now_trav | __ballot(phase == kPhaseDone))) break;
         if (!queue_empty && (uint32_t)__popcll(__ballot(phase == kPhaseIdle)) >= A.fill_threshold) break;
         }
     }

@@ -25,7 +25,7 @@ solo = bool(os.environ.get("PB_SOLO"))        # wait for every frame before the 
 for i in range(n):
     if vary: p.frame = 1000 + i
     ctx.render(p)
-    if solo: ctx.synchronize()
+    if solo and (i + 1) % B == 0: ctx.synchronize()      # wait for every launch (B frames) before the next is submitted
 ctx.synchronize()
 dt = time.perf_counter() - t0
 if os.environ.get("PB_RING"):
