@@ -58,6 +58,7 @@ struct RenderArgs {
     const uint4*  scene;        // the arena both arrays live in: triangle record t at byte 48 t, wide node i at byte node_off + 64 i;
                                 // child references are positions in it in 16-byte units (packed references, pt_host.h)
     uint32_t      node_off;
+    uint32_t      tri_gate3;    // 3 * numTris when the UBO's numTris is smaller than the uploaded triangle count (leaves past it are entered, not tested), else 0xFFFFFFFF
     // device scene, reference layouts (literal packet kernel, LBVH build, readback)
     const uint32_t* bvh4_ref;   // u32[1 + 8*M]   renderer.wgsl:91-111
     const float*    tris9;      // f32[9*N]       renderer.wgsl:82-89

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                 const float4 c = make_float4(__uint_as_float(n2.x), __uint_as_float(n2.y), __uint_as_float(n2.z), __uint_as_float(n2.w));
                 // a leaf whose triangle index is out of range points at the all-zero record behind the last triangle: the test
                 // below fails on |det| < eps, as if it had not been made (renderer.wgsl:262); only the counter has to know
-                if (STATS) { if ((S.cur & 0x7fffffffu) < 3u * A.num_tris) ++c_tris; }
+                if (STATS) { if ((S.cur & 0x7fffffffu) < 3u * A.num_tris) ++c_tris; }      // A.num_tris = the UBO's numTris <= uploaded
                 const F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
                 // branch-free Moller-Trumbore (renderer.wgsl:185-205): same operations and comparisons,
                 // rejections combined at the end, so the 48 B record is fetched in one go
@@ -330,7 +330,11 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                 const float v = inv_det * dot3(S.d, q);
                 const bool ok_v = !((v < 0.0f) | ((u + v) > 1.0f));
                 const float t = inv_det * dot3(e2, q);
-                if (ok_det & ok_u & ok_v & (t > kTriEps) & (t < S.best_t)) {
+                bool ok = ok_det & ok_u & ok_v & (t > kTriEps) & (t < S.best_t);
+                // the UBO's numTris may be smaller than the uploaded triangle count: `ti < numTris` (renderer.wgsl:267) then hides the
+                // triangles past it (a wavefront-uniform branch: the usual frame has numTris == uploaded and never takes it)
+                if (A.tri_gate3 != 0xFFFFFFFFu) ok &= (S.cur & 0x7fffffffu) < A.tri_gate3;
+                if (ok) {
                     S.best_t = t; S.best_tri = S.cur;
                     if (S.bounce & kShadowBit) phase = kPhaseDone;   // any-hit: first accepted hit ends the ray
                 }

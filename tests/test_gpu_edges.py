@@ -60,6 +60,42 @@ def test_num_tris_smaller_than_uploaded(rt, orc, gpu_ctx):
     assert same_bits(gpu_ctx.read_radiance(), ref)
 
 
+def test_num_tris_gate_and_out_of_range_leaves_in_path_mode(rt, orc, gpu_ctx):
+    """`ti < numTris` (renderer.wgsl:267) in the megakernel: (a) the UBO's numTris smaller than the uploaded count hides the
+    triangles past it, (b) a leaf of a supplied BVH4 whose triangle index is out of range is entered and tests nothing (the
+    wide layout points it at a never-hit record).  Image and counters equal the oracle's, instrumented kernel or not."""
+    tris = random_soup(700, 9)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    bvh4 = gpu_ctx.read_bvh4().copy()
+    kw = dict(mode=rt.PT_MODE_PATH, spp=2, max_bounces=4, seed=5, frame=2)
+    cam, quat = (0.1, 0.2, 2.6), (0, 0, 0, 1)
+
+    def check(num_tris, tree, what):
+        ref, _, ost = orc.render(orc.make_params(112, 72, num_tris, cam, quat, mode=orc_mod.MODE_PATH, spp=2, max_bounces=4, seed=5, frame=2), tris, tree)
+        p = gpu_ctx.make_params(112, 72, cam, quat, num_tris=num_tris, stats=True, **kw)
+        gpu_ctx.render(p)
+        assert same_bits(gpu_ctx.read_radiance(), ref), what
+        st = gpu_ctx.stats()
+        for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples", "max_stack"):
+            assert st[k] == ost[k], (what, k)
+        p.flags = 0
+        gpu_ctx.render(p)
+        assert same_bits(gpu_ctx.read_radiance(), ref), what + " (uninstrumented)"
+        p.flags = rt.PT_FLAG_SIMPLE_KERNEL
+        gpu_ctx.render(p)
+        assert same_bits(gpu_ctx.read_radiance(), ref), what + " (one pixel per lane)"
+
+    check(250, bvh4, "numTris 250 of 700")
+    # every fifth leaf gets a triangle index past the end
+    m = int(bvh4[0]); rec = bvh4[1:1 + 8 * m].reshape(m, 8)
+    leaves = np.nonzero(rec[:, 7] & 0x80000000)[0][::5]
+    rec[leaves, 7] = 0x80000000 | (700 + (leaves % 97))
+    gpu_ctx.set_bvh4(bvh4)
+    check(700, bvh4, "out-of-range leaves")
+    check(300, bvh4, "out-of-range leaves and numTris 300")
+
+
 def test_rgba8_and_tonemap_match_oracle(rt, orc, gpu_ctx):
     tris = rt.procedural_scene(0, 20000)
     gpu_ctx.set_triangles(tris)

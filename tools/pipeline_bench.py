@@ -4,7 +4,9 @@ import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 if os.environ.get("PB_TORCH"):
     import torch
-rt = importlib.import_module("raytracer-public_amd")
+# PB_BASE=1: the library of an earlier commit (tools/ab/raytracer_base: its __init__.py + libmi355pt.so, built by tools/ab/README) for same-session A/B
+if os.environ.get("PB_BASE"): sys.path.insert(0, os.path.join(ROOT, "tools", "ab")); rt = importlib.import_module("raytracer_base")
+else: rt = importlib.import_module("raytracer-public_amd")
 sponza = os.environ.get("PF_SCENE") == "sponza"      # config C4 instead of C2
 tris = rt.procedural_scene(1, 262144) if sponza else rt.procedural_scene(0, 871414)
 cam, quat = ((0.55, -0.05, 0.05), (0.0, 0.6630, 0.0, 0.7486)) if sponza else ((0, 0, 2.5), (0, 0, 0, 1))
