@@ -231,7 +231,16 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     // a tile-sharded frame is a fraction of the work: fewer, denser wavefronts (measured: 1/8 frame best at grid/4);
     // a batch of nf such frames is nf times the work again
     {
-        uint32_t div = PtTune::pick(ctx->tune.grid_div, count >= 8u ? 4u : (count >= 2u ? 2u : 1u));
+        // A single whole frame: the grid shrinks with the launches already in flight (one render() per frame without host waits,
+        // the reference's call shape: six frame slots, five neighbours, a quarter of the grid each -- 1.21 -> 1.01 ms per frame;
+        // a lone frame keeps the whole grid: 2.9 ms, 3.8 ms on a quarter of it).  tools/pipe_sweep.sh
+        uint32_t in_flight = 0;
+        if (count < 2u && nf == 1u && !stats)
+        {
+            for (int si = 0; si < ctx->num_slots; ++si) if (ctx->slots[si].used && hipEventQuery(ctx->slots[si].done) == hipErrorNotReady) ++in_flight;
+            (void)hipGetLastError();              // hipErrorNotReady is an answer, not an error: do not leave it behind for the launch checks
+        }
+        uint32_t div = PtTune::pick(ctx->tune.grid_div, count >= 8u ? 4u : (count >= 2u ? 2u : std::min(4u, 1u + in_flight)));
         if (nf > 1u) div = div > nf ? div / nf : 1u;
         if (div > 1u) grid = (grid + div - 1u) / div;
     }
@@ -318,7 +327,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small
     // sharded launches need several in flight to fill the chip.  Measured: tools/sweeps/tune13.sh, tools/sweeps/tune14.sh.
     const uint32_t work8 = nf * 8u / (count ? count : 1u);      // eighths of a whole frame
-    int want_slots = int(PtTune::pick(ctx->tune.slots, work8 >= 64u ? 2u : (work8 >= 16u ? PT_FRAME_SLOTS : (work8 >= 8u ? (sharded ? 4u : PT_FRAME_SLOTS) : (sharded ? 8u : PT_FRAME_SLOTS)))));
+    int want_slots = int(PtTune::pick(ctx->tune.slots, work8 >= 256u ? 3u : (work8 >= 64u ? 4u : (work8 >= 16u ? PT_FRAME_SLOTS : (work8 >= 8u ? (sharded ? 4u : 6u) : (sharded ? 8u : PT_FRAME_SLOTS))))));
     if (want_slots < 1) want_slots = 1;
     if (want_slots > PtContext::kMaxSlots) want_slots = PtContext::kMaxSlots;
     ctx->num_slots = want_slots;
