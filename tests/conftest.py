@@ -33,8 +33,10 @@ def rt():
     return importlib.import_module("raytracer-public_amd")
 
 
-@pytest.fixture(scope="session")
+@pytest.fixture
 def gpu_ctx(rt):
+    """A fresh context per test: batch size, external buffers, tile shares and accumulation state are per context, so nothing a
+    test sets (or leaves behind when it fails half way) reaches the next one."""
     ctx = rt.Context(0)
     yield ctx
     ctx.close()
