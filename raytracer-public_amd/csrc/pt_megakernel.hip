@@ -66,6 +66,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     unsigned long long* const stk = &lds_stack[wave][0][lane];          // entry i at stk[i * 64]: (tmin bits << 32) | ref
+    const uint32_t stk_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long*)stk;    // the same as an LDS byte address
     unsigned long long* const spill = (unsigned long long*)A.spill + ((size_t)blockIdx.x * PT_MEGA_BLOCK + threadIdx.x);   // entry j at spill[j * spill_stride]
     const size_t spill_stride = (size_t)gridDim.x * PT_MEGA_BLOCK;
 
@@ -394,19 +395,38 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
             if (need_pop && phase == kPhaseTrav) {
                 bool found = false;
                 // deep entries (index >= kShort) live in the spill area: rare
-                while (__builtin_expect(S.sp > kShort, 0)) {
-                    --S.sp;
-                    const unsigned long long e = *(volatile unsigned long long*)&spill[(size_t)(S.sp - kShort) * spill_stride];
-                    if (__uint_as_float((uint32_t)(e >> 32)) < S.best_t) { S.cur = (uint32_t)e; found = true; break; }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(S.sp > kShort) != 0ull, 0)) {     // wavefront-uniform: usually nobody is that deep
+                    while (S.sp > kShort) {
+                        --S.sp;
+                        const unsigned long long e = *(volatile unsigned long long*)&spill[(size_t)(S.sp - kShort) * spill_stride];
+                        if (__uint_as_float((uint32_t)(e >> 32)) < S.best_t) { S.cur = (uint32_t)e; found = true; break; }
+                    }
                 }
                 if (!found && S.sp > 0) {
-                    // entries whose box the ray no longer reaches (tmin >= best) are skipped: a lean loop that walks down the lane's
-                    // column of the LDS stack -- per entry one address step, one read, two compares
-                    int i = S.sp;
-                    unsigned long long e;
-                    do { --i; e = stk[i * 64]; found = __uint_as_float((uint32_t)(e >> 32)) < S.best_t; } while (!found && i > 0);
-                    S.sp = i;
-                    if (found) S.cur = (uint32_t)e;
+                    // Entries whose box the ray no longer reaches (tmin >= best) are skipped -- after a hit that is most of what a lane has
+                    // stacked, and the wavefront loops as long as its slowest lane.  The loop is hand-written: per entry one address
+                    // step, the read, two compares and three scalar instructions (lanes drop out of EXEC as they find their entry or run
+                    // out of entries); the compiler's form of the same loop costs 5 vector + 10 scalar instructions per entry.
+                    const uint32_t base = stk_lds, top = base + (uint32_t)S.sp * 512u;     // byte addresses: entry 0, one past the top entry
+                    uint32_t addr = top, lo, hi; unsigned long long saved_exec;
+                    asm volatile("s_mov_b64 %[save], exec\n"
+                                 "1:\n\t"
+                                 "v_add_u32 %[addr], 0xfffffe00, %[addr]\n\t"
+                                 "ds_read_b32 %[hi], %[addr] offset:4\n\t"
+                                 "ds_read_b32 %[lo], %[addr]\n\t"
+                                 "s_waitcnt lgkmcnt(0)\n\t"
+                                 "v_cmp_ngt_f32 vcc, %[best], %[hi]\n\t"         // not this one: go on
+                                 "s_and_b64 exec, exec, vcc\n\t"
+                                 "v_cmp_gt_u32 vcc, %[addr], %[base]\n\t"        // entries left below it
+                                 "s_and_b64 exec, exec, vcc\n\t"
+                                 "s_cbranch_execnz 1b\n\t"
+                                 "s_mov_b64 exec, %[save]"
+                                 : [addr] "+v"(addr), [lo] "=&v"(lo), [hi] "=&v"(hi), [save] "=&s"(saved_exec)
+                                 : [best] "v"(S.best_t), [base] "v"(base)
+                                 : "vcc", "memory");
+                    found = __uint_as_float(hi) < S.best_t;          // the entry the lane stopped at: its own, or entry 0 when it ran out
+                    S.sp = (int)((addr - base) >> 9);
+                    if (found) S.cur = lo;
                 }
                 // a camera ray that found nothing leaves its sample at the primed miss value (0 + 1 * 0.01, renderer.wgsl:410): no shade pass, the lane is free
                 if (!found) phase = (S.bounce == 0u && S.best_tri == kInvalidRef) ? kPhaseIdle : kPhaseDone;
