@@ -237,7 +237,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         uint32_t in_flight = 0;
         if (count < 2u && nf == 1u && !stats)
         {
-            for (int si = 0; si < ctx->num_slots; ++si) if (ctx->slots[si].used && hipEventQuery(ctx->slots[si].done) == hipErrorNotReady) ++in_flight;
+            for (const auto& o : ctx->slots) if (o.side && o.used && hipEventQuery(o.done) == hipErrorNotReady) ++in_flight;
             (void)hipGetLastError();              // hipErrorNotReady is an answer, not an error: do not leave it behind for the launch checks
         }
         uint32_t div = PtTune::pick(ctx->tune.grid_div, count >= 8u ? 4u : (count >= 2u ? 2u : std::min(4u, 1u + in_flight)));
@@ -326,10 +326,15 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
     // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small
     // sharded launches need several in flight to fill the chip.  Measured: tools/sweeps/tune13.sh, tools/sweeps/tune14.sh.
-    const uint32_t work8 = nf * 8u / (count ? count : 1u);      // eighths of a whole frame
-    int want_slots = int(PtTune::pick(ctx->tune.slots, work8 >= 256u ? 3u : (work8 >= 64u ? 4u : (work8 >= 16u ? PT_FRAME_SLOTS : (work8 >= 8u ? (sharded ? 4u : 6u) : (sharded ? 8u : PT_FRAME_SLOTS))))));
-    if (want_slots < 1) want_slots = 1;
-    if (want_slots > PtContext::kMaxSlots) want_slots = PtContext::kMaxSlots;
+    auto slots_for = [&](uint32_t frames) {
+        const uint32_t w8 = frames * 8u / (count ? count : 1u);      // eighths of a whole frame
+        int n = int(PtTune::pick(ctx->tune.slots, w8 >= 256u ? 3u : (w8 >= 64u ? 4u : (w8 >= 16u ? PT_FRAME_SLOTS : (w8 >= 8u ? (sharded ? 4u : 6u) : (sharded ? 8u : PT_FRAME_SLOTS))))));
+        return n < 1 ? 1 : (n > PtContext::kMaxSlots ? PtContext::kMaxSlots : n);
+    };
+    const int want_slots = slots_for(nf);
+    // slots are set up for what a FULL batch of the current setting rotates through as well: a partial launch (a warm-up, a
+    // flush before a read-back) must not leave the first full one to allocate and prime a slot
+    const int setup_slots = std::max(want_slots, slots_for(std::max(nf, ctx->batch_size)));
     ctx->num_slots = want_slots;
     // Every slot is sized for a full batch of the current setting (largest grid) and prefilled as a whole the first time
     // it is needed; from then on the resolve passes keep the buffers primed, whatever prefix a later launch uses.
@@ -338,7 +343,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     if (cap_samples > 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: batch too large (more than 2^32 samples per launch)");
     const uint32_t full_lanes = ptk::megakernel_grid(cus) * ptk::megakernel_block();
     A.pool_capacity = full_lanes * 2u;           // donations can repeat; a full pool just stops donating
-    for (int si = 0; si < (stats ? 1 : want_slots); ++si) {
+    for (int si = 0; si < (stats ? 1 : setup_slots); ++si) {
         PtContext::FrameSlot& s = ctx->slots[si];
         if (!s.side) {
             PT_HIP(ctx, hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
@@ -397,6 +402,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
             std::memcpy(sl.cull_key, key, sizeof key); sl.cull_valid = true; sl.num_trace_tiles = A.num_trace_tiles;
         }
         A.trace_slots = sl.trace_slots.ptr;
+        A.trace_rect[0] = rect.tx0; A.trace_rect[1] = rect.tx1; A.trace_rect[2] = rect.ty0; A.trace_rect[3] = rect.ty1;
     }
     if (stats) {
         // the counter blocks are zeroed on the stream the instrumented kernel runs on, behind everything that stream still has

@@ -90,6 +90,7 @@ struct RenderArgs {
     // provably misses the root box are left out (pt_api.cpp: screen rectangle of the root box) and keep the primed miss value.
     // Samples are stored by (frame, owned-tile slot, sample), whatever subset is traced.
     const uint32_t* trace_slots; uint32_t num_trace_tiles;
+    uint32_t  trace_rect[4];                  // tiles [tx0, tx1) x [ty0, ty1) that are traced when trace_slots is set: the rest keeps the primed value (resolve_kernel writes it without reading)
     uint32_t  trace_bpf, trace_bpf_magic;     // traced batches per frame (num_trace_tiles * spp) and floor(2^32 / that)
     uint32_t  spp_magic, tiles_x_magic;       // floor(2^32 / spp), floor(2^32 / tiles_x): division by multiply + one correction
     uint32_t  num_sample_batches;             // (frame, owned tile, sample) batches in the sample buffer = num_frames * batches_per_frame

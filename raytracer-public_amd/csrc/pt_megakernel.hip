@@ -479,9 +479,17 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
     const FrameParams* const frames = A.frames;
     float4* const* const outs = A.outs;
     const uint32_t f_begin = ACCUM ? 0u : blockIdx.y, f_end = ACCUM ? A.num_frames : blockIdx.y + 1u;
+    // a tile outside the traced rectangle (every camera ray provably misses the root box, pt_api.cpp) was never touched by the
+    // trace: its samples are the primed value, which is summed from a register -- nothing is read and nothing needs re-priming
+    // (the same additions in the same order, so the same bits).  For the dragon-class frame that is two thirds of the pass's traffic.
+    const bool untraced = A.trace_slots != nullptr && !(tx >= A.trace_rect[0] && tx < A.trace_rect[1] && ty >= A.trace_rect[2] && ty < A.trace_rect[3]);
     for (uint32_t fid = f_begin; fid < f_end; ++fid) {
         F3 sum = f3(0.0f, 0.0f, 0.0f);
         float4* const sp = A.samples + (((size_t)fid * A.batches_per_frame + (size_t)slot * A.spp) * 64u + p);   // sample s at sp[s * 64]
+        if (untraced) {
+            if (!ACCUM && (frames[fid].accum_mode & 0x100u)) continue;
+            for (uint32_t s = 0; s < A.spp; ++s) sum = sum + f3(bg, bg, bg);
+        } else {
         if (!ACCUM) {
             // independent frames resolve in parallel; where several share one output target the last submitted one is the
             // result (what resolving them in order would leave), the others only hand their sample slots back
@@ -499,6 +507,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
             for (uint32_t j = 0; j < 4u; ++j) if (j < n) sum = sum + f3(v[j].x, v[j].y, v[j].z);
 #pragma unroll
             for (uint32_t j = 0; j < 4u; ++j) if (j < n) sp[(size_t)(s0 + j) * 64u] = prime;     // leave the slot primed for its next frame (no separate prefill pass)
+        }
         }
         float count = (float)A.spp;
         if (ACCUM) {
