@@ -96,7 +96,7 @@ struct PtContext {
     // dense start of the next; the resolve passes stay in call order on the main stream.
     struct FrameSlot {
         hipStream_t side = nullptr; hipEvent_t resolved = nullptr, done = nullptr; bool used = false;
-        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<float4> cont; DevBuf<uint32_t> flags;
+        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<uint4> rays; DevBuf<float4> cont; DevBuf<uint32_t> flags;
         // owned-tile slots that the launch in this slot traces (the others are culled: every camera ray misses the root box)
         DevBuf<uint32_t> trace_slots; uint32_t* h_trace = nullptr; size_t h_trace_cap = 0; hipEvent_t trace_copied = nullptr;
         uint32_t cull_key[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t num_trace_tiles = 0; bool cull_valid = false;
@@ -305,6 +305,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     if (uint64_t(A.perm_cols) * A.perm_rows * 64ull > 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: batch too large (more than 2^32 items per launch)");
     A.total_items = A.perm_cols * A.perm_rows * 64u;
     A.chunk_items = PtTune::pick(ctx->tune.chunk, 512u);
+    A.chunk_items = ((A.chunk_items + 63u) / 64u) * 64u;           // whole batches of 64: the kernel generates camera rays a batch at a time
     if (A.chunk_items < 64u) A.chunk_items = 64u;
     // every wavefront adds chunk_items to a 32-bit cursor once more after it has found the queue dry (once per XCD range with
     // the XCD-aware queue): the cursor must not wrap, or items would be handed out twice and the launch would never end
@@ -353,6 +354,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         PT_HIP(ctx, s.queue.ensure(16));
         PT_HIP(ctx, s.samples.ensure(cap_samples));
         PT_HIP(ctx, s.spill.ensure(size_t(full_lanes) * size_t(64 - PT_SHORT_STACK)));
+        PT_HIP(ctx, s.rays.ensure(size_t(full_lanes) * 3u));          // 64 ray records of 3 x uint4 per wavefront
         PT_HIP(ctx, s.cont.ensure(A.cont_passes ? size_t(A.pool_capacity) * 4u * 2u : 4u));
         PT_HIP(ctx, s.flags.ensure(A.cont_passes ? size_t(A.pool_capacity) * 2u : 4u));
         PT_HIP(ctx, s.frame_params.ensure(std::max<size_t>(ctx->batch_size, nf))); PT_HIP(ctx, s.frame_outs.ensure(std::max<size_t>(ctx->batch_size, nf)));
@@ -364,7 +366,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     }
     PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(want_slots))];
     A.prime = stats ? 1u : 0u;                   // instrumented launches start from a freshly primed prefix
-    A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr;
+    A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.raybuf = sl.rays.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr;
     A.trace_slots = nullptr;
     if (cull) {
         // the list travels through a pinned staging buffer of the slot; it is rebuilt only when the rectangle (or the tile share) changes
@@ -494,7 +496,7 @@ void pt_destroy(PtContext* ctx) {
     ctx->d_subtree.release(); ctx->d_ids.release(); ctx->d_bnd.release(); ctx->d_child_pos.release(); ctx->d_build_temp.release();
     if (ctx->h_word) (void)hipHostFree(ctx->h_word);
     for (auto& sl : ctx->slots) {
-        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.trace_slots.release();
+        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.rays.release(); sl.trace_slots.release();
         if (sl.h_trace) (void)hipHostFree(sl.h_trace);
         if (sl.trace_copied) (void)hipEventDestroy(sl.trace_copied); sl.cont.release(); sl.flags.release(); sl.frame_params.release(); sl.frame_outs.release();
         if (sl.resolved) (void)hipEventDestroy(sl.resolved);

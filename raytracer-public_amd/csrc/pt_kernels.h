@@ -84,6 +84,7 @@ struct RenderArgs {
     float4*   samples;          // per-sample radiance, item = (slot*spp + s)*64 + lane_in_tile
     uint32_t* queue;            // global item cursor
     uint2*    spill;            // deep stack entries: [entry][grid lane]
+    uint4*    raybuf;           // per wavefront of the grid: 64 camera-ray records of 3 x uint4 (o, d, inv, key, sample index), generated 64 at a time
     unsigned long long* wave_times;   // STATS diagnostics: 8 words per wave (begin, queue-empty, end ticks @100 MHz, loop counts)
     // Queue enumeration vs sample storage.  The queue hands out (frame, traced tile, sample) batches of 64 pixel-samples;
     // `trace_slots` lists the owned-tile slots that are traced at all (nullptr = every owned tile): tiles whose every camera ray

@@ -124,12 +124,41 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
         return true;
     };
 
+    // the wavefront's ray buffer (camera rays generated 64 at a time, see the refill pass): 64 records of 3 x uint4
+    uint4* const rb = CONT ? nullptr : A.raybuf + ((size_t)blockIdx.x * (PT_MEGA_BLOCK / 64) + wave) * (64 * 3);
+    uint32_t rb_next = 0, rb_count = 0;       // wave-uniform
+    // nothing left to start: the queue is dry and (pass 0) so is the ray buffer
+    auto source_dry = [&]() -> bool { return queue_empty && (CONT || rb_next == rb_count); };
+    // claim the next chunk of the queue (one atomic per wavefront and chunk); sets queue_empty when there is none
+    auto claim_chunk = [&]() {
+        if (!CONT && A.xcd_span != 0u) {
+            // XCD-aware queue: the logical item space is cut into 8 contiguous ranges, one cursor each; a wavefront
+            // works through the range of the XCD it runs on (its neighbours in the queue order are then traced by
+            // wavefronts that share its L2) and moves on to the next XCD's range when its own has run dry
+            for (;;) {
+                const uint32_t qi = (xcc + xcd_hop) & 7u;
+                const uint32_t q_begin = qi * A.xcd_span;
+                const uint32_t q_end = min(q_begin + A.xcd_span, total_items);
+                uint32_t start = 0;
+                if (lane == 0) start = atomicAdd(A.queue + 8 + qi, chunk_items);
+                start = __builtin_amdgcn_readfirstlane(start);
+                if (q_begin < q_end && start < q_end - q_begin) { chunk_next = q_begin + start; chunk_end = min(chunk_next + chunk_items, q_end); break; }
+                if (++xcd_hop == 8u) { queue_empty = true; PT_TAIL_PRIO; if (STATS) { t_qempty = wall_clock64(); n_iter_q = n_iter; lanes_sum_q = lanes_sum; } break; }
+            }
+        } else {
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(A.queue, chunk_items);
+            start = __builtin_amdgcn_readfirstlane(start);
+            if (start >= total_items) { queue_empty = true; PT_TAIL_PRIO; if (STATS) { t_qempty = wall_clock64(); n_iter_q = n_iter; lanes_sum_q = lanes_sum; } }
+            else { chunk_next = start; chunk_end = min(start + chunk_items, total_items); }
+        }
+    };
     // Lanes whose ray has ended wait for a shade pass until shade_threshold of them are there: the pass costs a wavefront as much
     // as 1.5 traversal steps whatever the number of lanes in it.  Once the queue is dry a wavefront thins out, and a lane that
     // waited for a crowd would wait for the other lanes' whole rays -- the paths of a wavefront would run one after the other,
     // and it is the longest chain of dependent steps that ends a launch.  So then a quarter of the live lanes is enough.
     auto shade_due = [&](unsigned long long m_live) -> uint32_t {
-        if (!queue_empty) return A.shade_threshold;
+        if (!source_dry()) return A.shade_threshold;
         const uint32_t q = (uint32_t)__popcll(m_live) >> 2;
         return q < 1u ? 1u : (q < A.shade_threshold ? q : A.shade_threshold);
     };
@@ -142,7 +171,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                 if (STATS) { ++n_shade; cy_mark = __builtin_amdgcn_s_memtime(); }
                 // sparse wavefront and nothing left to regenerate from: hand the surviving paths to the
                 // next pass (at a closest-ray boundary) instead of finishing them at low lane utilisation
-                const bool flush_now = pool_on && queue_empty && (uint32_t)__popcll(__ballot(phase != kPhaseIdle)) < A.flush_threshold;
+                const bool flush_now = pool_on && source_dry() && (uint32_t)__popcll(__ballot(phase != kPhaseIdle)) < A.flush_threshold;
                 bool do_flush = false;
                 if (phase == kPhaseDone) {
                     const bool hit = S.best_tri != kInvalidRef;
@@ -228,38 +257,15 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
         {
             const unsigned long long m_idle = __ballot(phase == kPhaseIdle);
             const unsigned long long m_trav = __ballot(phase == kPhaseTrav);
-            if (m_idle != 0ull && !queue_empty && ((uint32_t)__popcll(m_idle) >= A.fill_threshold || m_trav == 0ull)) {
+            if (m_idle != 0ull && !source_dry() && ((uint32_t)__popcll(m_idle) >= A.fill_threshold || m_trav == 0ull)) {
                 const uint32_t want = (uint32_t)__popcll(m_idle);
+                const uint32_t rank = (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull));
                 if (STATS) { ++n_fill; cy_mark = __builtin_amdgcn_s_memtime(); }
-                if (chunk_end - chunk_next < want && chunk_next == chunk_end) {
-                    // claim a new chunk (one atomic per wave and chunk)
-                    if (!CONT && A.xcd_span != 0u) {
-                        // XCD-aware queue: the logical item space is cut into 8 contiguous ranges, one cursor each; a wavefront
-                        // works through the range of the XCD it runs on (its neighbours in the queue order are then traced by
-                        // wavefronts that share its L2) and moves on to the next XCD's range when its own has run dry
-                        for (;;) {
-                            const uint32_t qi = (xcc + xcd_hop) & 7u;
-                            const uint32_t q_begin = qi * A.xcd_span;
-                            const uint32_t q_end = min(q_begin + A.xcd_span, total_items);
-                            uint32_t start = 0;
-                            if (lane == 0) start = atomicAdd(A.queue + 8 + qi, chunk_items);
-                            start = __builtin_amdgcn_readfirstlane(start);
-                            if (q_begin < q_end && start < q_end - q_begin) { chunk_next = q_begin + start; chunk_end = min(chunk_next + chunk_items, q_end); break; }
-                            if (++xcd_hop == 8u) { queue_empty = true; PT_TAIL_PRIO; if (STATS) { t_qempty = wall_clock64(); n_iter_q = n_iter; lanes_sum_q = lanes_sum; } break; }
-                        }
-                    } else {
-                    uint32_t start = 0;
-                    if (lane == 0) start = atomicAdd(A.queue, chunk_items);
-                    start = __builtin_amdgcn_readfirstlane(start);
-                    if (start >= total_items) { queue_empty = true; PT_TAIL_PRIO; if (STATS) { t_qempty = wall_clock64(); n_iter_q = n_iter; lanes_sum_q = lanes_sum; } }
-                    else { chunk_next = start; chunk_end = min(start + chunk_items, total_items); }
-                    }
-                }
-                if (!queue_empty) {
-                    const uint32_t rank = (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull));
-                    const uint32_t avail = chunk_end - chunk_next;
-                    if (phase == kPhaseIdle && rank < avail) {
-                        if (CONT) {
+                if (CONT) {
+                    if (chunk_next == chunk_end) claim_chunk();
+                    if (!queue_empty) {
+                        const uint32_t avail = chunk_end - chunk_next;
+                        if (phase == kPhaseIdle && rank < avail) {
                             const float4* rec = A.in_pool + (size_t)(in_base + chunk_next + rank) * 4;
                             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                             S.o = f3(r0.x, r0.y, r0.z); S.d = f3(r0.w, r1.x, r1.y); S.inv = safe_inv(S.d);
@@ -267,24 +273,57 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                             S.key = __float_as_uint(r3.x); S.item = __float_as_uint(r3.y); S.bounce = __float_as_uint(r3.z);
                             if (STATS) ++c_closest;
                             phase = begin_ray() ? kPhaseTrav : kPhaseDone;
-                        } else {
-                        const ItemInfo it = decode_item(A, chunk_next + rank);
-                        if (it.valid) {
-                            const uint32_t fid = it.fid, px = it.px, py = it.py, s = it.s, item = it.sample_index;
-                            const FrameParams fp = frames[fid];
-                            const uint32_t key = sample_key(fp.seed, py * A.width + px, fp.frame * A.spp + s);
-                            const Ray r = primary_ray_fp(A, fp, (float)px + rnd(key, 0, 0), (float)py + rnd(key, 0, 1));
-                            S.o = r.o; S.d = r.d; S.inv = r.inv;
-                            S.key = key; S.item = item; S.bounce = 0u;
-                            S.T = f3(1.0f, 1.0f, 1.0f); S.rad = f3(0.0f, 0.0f, 0.0f);
-                            if (STATS) { ++c_closest; ++c_samples; }
-                            // a camera ray that misses the root box keeps the prefilled sample value
-                            // (0 + 1 * 0.01, renderer.wgsl:410) and the lane stays idle
-                            if (begin_ray()) phase = kPhaseTrav;
                         }
-                        }
+                        chunk_next += min(want, avail);
                     }
-                    chunk_next += min(want, avail);
+                } else {
+                    // Camera rays are GENERATED by the whole wavefront, one (frame, tile, sample) batch of 64 at a time -- item decode,
+                    // RNG key, jittered ray, its rotation, the three correctly rounded reciprocals and the root-box test are ~300
+                    // instructions whether 8 lanes need a ray or 64, so all 64 lanes compute (whatever their own ray is doing: only
+                    // temporaries are touched), and the rays that enter the root box go, compacted, into the wavefront's ray buffer.
+                    // Idle lanes then only FETCH a ready ray (three dwordx4).  A camera ray that misses the root box is never stored:
+                    // its sample keeps the primed miss value (0 + 1 * 0.01, renderer.wgsl:410).
+                    while (rb_next == rb_count && !queue_empty) {
+                        if (chunk_next == chunk_end) claim_chunk();
+                        if (queue_empty) break;
+                        const uint32_t first = chunk_next; chunk_next += 64u;       // chunks are multiples of 64 items
+                        const ItemInfo it = decode_item(A, first + lane);
+                        bool enters = false; Ray r; uint32_t key = 0u;
+                        r.o = r.d = r.inv = f3(0.0f, 0.0f, 0.0f);
+                        if (it.valid) {
+                            const FrameParams fp = frames[it.fid];
+                            key = sample_key(fp.seed, it.py * A.width + it.px, fp.frame * A.spp + it.s);
+                            r = primary_ray_fp(A, fp, (float)it.px + rnd(key, 0, 0), (float)it.py + rnd(key, 0, 1));
+                            if (STATS) { ++c_closest; ++c_samples; }
+                            if (!scene_empty) {
+                                if (STATS) { c_nodes += 1; if (c_maxstack < 1u) c_maxstack = 1u; }   // the root record is fetched before its degenerate check (renderer.wgsl:240-244)
+                                float troot;
+                                if (A.root_degenerate == 0u) enters = slab(r, A.root_box[0], A.root_box[1], A.root_box[2], kInfT, troot);
+                            }
+                        }
+                        const unsigned long long m_in = __ballot(enters);
+                        if (enters) {
+                            uint4* rec = rb + (size_t)__popcll(m_in & ((1ull << lane) - 1ull)) * 3;
+                            rec[0] = make_uint4(__float_as_uint(r.o.x), __float_as_uint(r.o.y), __float_as_uint(r.o.z), __float_as_uint(r.d.x));
+                            rec[1] = make_uint4(__float_as_uint(r.d.y), __float_as_uint(r.d.z), __float_as_uint(r.inv.x), __float_as_uint(r.inv.y));
+                            rec[2] = make_uint4(__float_as_uint(r.inv.z), key, it.sample_index, 0u);
+                        }
+                        rb_count = (uint32_t)__popcll(m_in); rb_next = 0u;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the records are written before any lane of this wavefront fetches one
+                    }
+                    const uint32_t avail = rb_count - rb_next;
+                    if (phase == kPhaseIdle && rank < avail) {
+                        const uint4* rec = rb + (size_t)(rb_next + rank) * 3;
+                        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                        S.o = f3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+                        S.d = f3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+                        S.inv = f3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+                        S.key = r2.y; S.item = r2.z; S.bounce = 0u;
+                        S.T = f3(1.0f, 1.0f, 1.0f); S.rad = f3(0.0f, 0.0f, 0.0f);
+                        S.best_t = kInfT; S.best_tri = kInvalidRef; S.sp = 0; S.cur = A.root_ref; S.sel = ray_selectors(S.inv);
+                        phase = kPhaseTrav;
+                    }
+                    rb_next += min(want, avail);
                 }
                 if (STATS) cy_fill += __builtin_amdgcn_s_memtime() - cy_mark;
             }
@@ -293,7 +332,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
         const unsigned long long m_trav = __ballot(phase == kPhaseTrav);
         if (m_trav == 0ull) {
             const unsigned long long m_done = __ballot(phase == kPhaseDone);
-            if (m_done == 0ull && queue_empty) break;    // donated paths are picked up by the continuation pass
+            if (m_done == 0ull && source_dry()) break;    // donated paths are picked up by the continuation pass
             continue;
         }
         // ------------------------------------------------------------------ traversal steps, until one of the passes above is due again
@@ -437,7 +476,7 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
         const unsigned long long now_trav = __ballot(phase == kPhaseTrav);
         if (now_trav == 0ull) break;
         if ((uint32_t)__popcll(__ballot(phase == kPhaseDone)) >= shade_due(now_trav | __ballot(phase == kPhaseDone))) break;
-        if (!queue_empty && (uint32_t)__popcll(__ballot(phase == kPhaseIdle)) >= A.fill_threshold) break;
+        if (!source_dry() && (uint32_t)__popcll(__ballot(phase == kPhaseIdle)) >= A.fill_threshold) break;
         }
     }
     if (STATS) {
