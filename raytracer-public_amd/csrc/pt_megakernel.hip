@@ -401,7 +401,8 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                 // equals it is a hit slot)
                 const unsigned long long Q0 = __builtin_amdgcn_ballot_w64(e0 == tn), Q1 = __builtin_amdgcn_ballot_w64(e1 == tn), Q2 = __builtin_amdgcn_ballot_w64(e2 == tn);
                 const unsigned long long M1 = Q1 & ~Q0, M2 = Q2 & ~(Q0 | Q1), M3 = ~(Q0 | Q1 | Q2);
-                const uint32_t rn = lane_of(Q0) ? n3.x : lane_of(M1) ? n3.y : lane_of(M2) ? n3.z : n3.w;
+                uint32_t rn = n3.x;                                   // three independent selects (a nested ?: becomes branches)
+                rn = lane_of(M1) ? n3.y : rn; rn = lane_of(M2) ? n3.z : rn; rn = lane_of(M3) ? n3.w : rn;
                 if (lane_of(H0 | H1 | H2 | H3)) {
                     // slot s (1..3) is stacked iff it is hit and an earlier slot is hit too (so it is not the first hit); the first hit
                     // among the slots before s is then what the nearest slot hands over
