@@ -40,17 +40,17 @@ struct DevBuf {
 // tests and tools/sweep.sh change them through pt_debug_set_tune.
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
-    uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto, leaf = kAuto,
+    uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto,
              flush = kAuto, passes = kAuto, slots = kAuto, cull = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"LEAF", &PtTune::leaf}, {"FLUSH", &PtTune::flush}, {"PASSES", &PtTune::passes}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}};
+            {"FILL", &PtTune::fill}, {"FLUSH", &PtTune::flush}, {"PASSES", &PtTune::passes}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "LEAF", "FLUSH", "PASSES", "SLOTS", "CULL"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "FLUSH", "PASSES", "SLOTS", "CULL"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -320,7 +320,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         const uint32_t work8_q = nf * 8u / (count ? count : 1u);
         A.xcd_span = PtTune::pick(ctx->tune.xcd, work8_q >= 64u ? 1u : 0u) ? ((per + A.chunk_items - 1u) / A.chunk_items) * A.chunk_items : 0u;
     }
-    A.shade_threshold = PtTune::pick(ctx->tune.shade, PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD); A.leaf_threshold = PtTune::pick(ctx->tune.leaf, PT_LEAF_THRESHOLD);
+    A.shade_threshold = PtTune::pick(ctx->tune.shade, PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD);
     A.flush_threshold = PtTune::pick(ctx->tune.flush, sharded ? 0u : PT_FLUSH_THRESHOLD);   // sharded frames are too small to profit from a second pass
     A.cont_passes = PtTune::pick(ctx->tune.passes, PT_MAX_CONT_PASSES);
     // frame slot (instrumented launches always use slot 0 and are not overlapped)

@@ -29,9 +29,6 @@
 #ifndef PT_MAX_CONT_PASSES
 #define PT_MAX_CONT_PASSES 1       // continuation passes after pass 0 (the last one runs every path to its end)
 #endif
-#ifndef PT_LEAF_THRESHOLD
-#define PT_LEAF_THRESHOLD 1        // >1 postpones the triangle test until that many lanes wait at a leaf (measured slower: the step is latency-, not issue-bound)
-#endif
 #ifndef PT_FILL_THRESHOLD
 #define PT_FILL_THRESHOLD 4        // hand out ready camera rays when this many lanes of a wavefront are without a path (a fetch from the ray buffer is cheap: 4 beats 8 by 2 %)
 #endif
@@ -104,7 +101,7 @@ struct RenderArgs {
     float4*   pool; uint32_t* pool_flags; uint32_t* pool_ctrl;      // ctrl: [0] reserved tail, [1] claimed head
     const float4* in_pool; const uint32_t* in_ctrl;                  // previous pass's pool (continuation passes)
     uint32_t  pool_capacity, flush_threshold, cont_passes;
-    uint32_t  shade_threshold, fill_threshold, leaf_threshold;
+    uint32_t  shade_threshold, fill_threshold;
     // batched launch: frames[i] / outs[i] for i < num_frames; items of frame i are batches [i*batches_per_frame, ...)
     const FrameParams* frames; float4* const* outs;     // device arrays of the frame slot, filled by launch_frame_params
     uint32_t  num_frames, batches_per_frame;
