@@ -78,7 +78,7 @@ struct RenderArgs {
     // extension
     uint32_t spp, max_bounces, seed, accumulate, compact;
     // persistent megakernel
-    float4*   samples;          // per-sample radiance, item = (slot*spp + s)*64 + lane_in_tile
+    float4*   samples;          // per-sample radiance, item = (slot*spp + s)*64 + lane_in_tile; primed per batch by the trace (camera-ray generation), read by resolve_kernel
     uint32_t* queue;            // global item cursor
     uint2*    spill;            // deep stack entries: [entry][grid lane]
     uint4*    raybuf;           // per wavefront of the grid: 64 camera-ray records of 3 x uint4 (o, d, inv, key, sample index), generated 64 at a time
@@ -105,7 +105,7 @@ struct RenderArgs {
     // batched launch: frames[i] / outs[i] for i < num_frames; items of frame i are batches [i*batches_per_frame, ...)
     const FrameParams* frames; float4* const* outs;     // device arrays of the frame slot, filled by launch_frame_params
     uint32_t  num_frames, batches_per_frame;
-    uint32_t  prime;            // 1: launch_trace must zero the control block and prefill the samples itself
+    uint32_t  prime;            // 1: launch_trace must zero the control block itself
 };
 
 hipError_t launch_render(const RenderArgs& args, int kmode, bool stats, hipStream_t stream);

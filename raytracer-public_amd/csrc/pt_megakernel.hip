@@ -291,6 +291,10 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
                         bool enters = false; Ray r; uint32_t key = 0u;
                         r.o = r.d = r.inv = f3(0.0f, 0.0f, 0.0f);
                         if (it.valid) {
+                            // every sample of the batch starts as the camera-ray miss value (0 + 1 * 0.01, renderer.wgsl:410); a path that
+                            // hits something overwrites its own later (same wavefront, same address: in order).  Priming here, 64 lanes
+                            // at a time, is what keeps the resolve pass read-only on the sample buffer.
+                            A.samples[it.sample_index] = make_float4(0.0f + 1.0f * kBgPrimary, 0.0f + 1.0f * kBgPrimary, 0.0f + 1.0f * kBgPrimary, 1.0f);
                             const FrameParams fp = frames[it.fid];
                             key = sample_key(fp.seed, it.py * A.width + it.px, fp.frame * A.spp + it.s);
                             r = primary_ray_fp(A, fp, (float)it.px + rnd(key, 0, 0), (float)it.py + rnd(key, 0, 1));
@@ -501,8 +505,9 @@ __global__ __launch_bounds__(PT_MEGA_BLOCK, PT_MEGA_WAVES_PER_SIMD) void trace_p
 
 // Sum the samples of each owned pixel in sample order; carry the running sum when accumulating.  blockIdx.y = frame of
 // the batch when the frames are independent (ACCUM false); an accumulating sequence walks its frames in submission order
-// (the running sum is order dependent).  Samples are read four at a time before their slots are re-primed, so a wavefront
-// keeps several loads in flight: the pass runs next to a persistent launch that leaves it about one wave slot per SIMD.
+// (the running sum is order dependent).  Samples are read four at a time, so a wavefront keeps several loads in flight: the
+// pass runs next to a persistent launch that leaves it about one wave slot per SIMD.  It only READS the sample buffer: the trace
+// primes every batch it generates.
 template <bool ACCUM>
 __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -515,12 +520,11 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
     if (px >= A.width || py >= A.height) return;
     const size_t out_index = A.compact ? (size_t)idx : ((size_t)py * A.width + px);
     const float bg = 0.0f + 1.0f * kBgPrimary;
-    const float4 prime = make_float4(bg, bg, bg, 1.0f);
     const FrameParams* const frames = A.frames;
     float4* const* const outs = A.outs;
     const uint32_t f_begin = ACCUM ? 0u : blockIdx.y, f_end = ACCUM ? A.num_frames : blockIdx.y + 1u;
     // a tile outside the traced rectangle (every camera ray provably misses the root box, pt_api.cpp) was never touched by the
-    // trace: its samples are the primed value, which is summed from a register -- nothing is read and nothing needs re-priming
+    // trace: its samples would be the primed value, which is summed from a register -- nothing is read
     // (the same additions in the same order, so the same bits).  For the dragon-class frame that is two thirds of the pass's traffic.
     const bool untraced = A.trace_slots != nullptr && !(tx >= A.trace_rect[0] && tx < A.trace_rect[1] && ty >= A.trace_rect[2] && ty < A.trace_rect[3]);
     for (uint32_t fid = f_begin; fid < f_end; ++fid) {
@@ -533,10 +537,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
         if (!ACCUM) {
             // independent frames resolve in parallel; where several share one output target the last submitted one is the
             // result (what resolving them in order would leave), the others only hand their sample slots back
-            if (frames[fid].accum_mode & 0x100u) {
-                for (uint32_t s = 0; s < A.spp; ++s) sp[(size_t)s * 64u] = prime;
-                continue;
-            }
+            if (frames[fid].accum_mode & 0x100u) continue;
         }
         for (uint32_t s0 = 0; s0 < A.spp; s0 += 4u) {
             const uint32_t n = min(4u, A.spp - s0);
@@ -545,8 +546,6 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
             for (uint32_t j = 0; j < 4u; ++j) v[j] = (j < n) ? sp[(size_t)(s0 + j) * 64u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
             for (uint32_t j = 0; j < 4u; ++j) if (j < n) sum = sum + f3(v[j].x, v[j].y, v[j].z);
-#pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) if (j < n) sp[(size_t)(s0 + j) * 64u] = prime;     // leave the slot primed for its next frame (no separate prefill pass)
         }
         }
         float count = (float)A.spp;
@@ -562,27 +561,17 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs A) {
     }
 }
 
-// every sample starts as the camera-ray miss value 0 + 1 * 0.01 (renderer.wgsl:410)
-__global__ __launch_bounds__(256) void prefill_samples_kernel(float4* __restrict__ samples, uint32_t n) {
-    const float v = 0.0f + 1.0f * kBgPrimary;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        samples[i] = make_float4(v, v, v, 1.0f);
-}
-
-// Trace phase of one frame (prefill + pass 0 + continuation passes) on `stream`; k0/k1 (optional)
+// Trace phase of one frame (pass 0 + continuation passes) on `stream`; k0/k1 (optional)
 // are recorded immediately around the trace_paths_kernel launches.
 hipError_t launch_trace(const RenderArgs& A0, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1) {
     RenderArgs A = A0;
     hipError_t e = hipSuccess;
     if (A.total_items == 0u) return hipSuccess;
     if (A0.prime) {
-        // first use of this slot's buffers (or a new frame shape): zero the control block and prefill the sample
-        // buffer; afterwards resolve_kernel leaves both ready for the slot's next frame
+        // first use of this slot's control block: zero it; afterwards resolve_kernel rewinds it for the slot's next launch.  (The
+        // sample buffer needs no preparation: the trace primes every batch it generates, and nothing else is ever read.)
         e = hipMemsetAsync(A.queue, 0, 16 * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
-        const uint32_t n_samples = A.num_sample_batches * 64u;
-        hipLaunchKernelGGL(prefill_samples_kernel, dim3(2048), dim3(256), 0, stream, A.samples, n_samples);
-        e = hipGetLastError(); if (e != hipSuccess) return e;
     }
     // control block (u32): [0..3] item cursors of the passes; [4],[5] tail/head of pool A; [6],[7] tail/head of pool B
     uint32_t* const ctrl = A0.queue;
@@ -645,10 +634,8 @@ hipError_t launch_frame_params(const FrameParams* frames, float4* const* outs, u
 }
 
 hipError_t launch_prime(uint32_t* queue, float4* samples, uint32_t n_samples, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(queue, 0, 16 * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    if (n_samples) hipLaunchKernelGGL(prefill_samples_kernel, dim3(2048), dim3(256), 0, stream, samples, n_samples);
-    return hipGetLastError();
+    (void)samples; (void)n_samples;       // the trace primes the samples of every batch it generates
+    return hipMemsetAsync(queue, 0, 16 * sizeof(uint32_t), stream);
 }
 
 uint32_t megakernel_grid(int num_cus) { return (uint32_t)num_cus * PT_MEGA_WAVES_PER_SIMD * (256 / PT_MEGA_BLOCK); }
