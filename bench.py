@@ -53,11 +53,21 @@ KERNEL_SOURCES = ["pt_megakernel.hip", "pt_device.h", "pt_kernels.h"]
 VERIFY_STEP = 16
 
 
+def _normalised_source(path):
+    """Kernel source without // comments, trailing blanks and empty lines: a comment edit must not make the counter file look stale."""
+    out = []
+    for line in open(path, "r", encoding="utf-8", errors="replace"):
+        code = line.split("//", 1)[0].rstrip()
+        if code:
+            out.append(code)
+    return "\n".join(out).encode()
+
+
 def source_tag():
     """Identifies the kernel build the PMC summary was taken from."""
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, "raytracer-public_amd", "csrc", f), "rb").read())
+        h.update(_normalised_source(os.path.join(ROOT, "raytracer-public_amd", "csrc", f)))
     return h.hexdigest()[:16]
 
 

@@ -7,10 +7,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "trace_paths_kernel<false, false>"
 
 
+def _normalised_source(path):
+    """Kernel source without // comments, trailing blanks and empty lines: a comment edit must not make the counter file look stale."""
+    out = []
+    for line in open(path, "r", encoding="utf-8", errors="replace"):
+        code = line.split("//", 1)[0].rstrip()
+        if code:
+            out.append(code)
+    return "\n".join(out).encode()
+
+
 def source_tag():
     h = hashlib.sha256()
     for f in ("pt_megakernel.hip", "pt_device.h", "pt_kernels.h"):
-        h.update(open(os.path.join(ROOT, "raytracer-public_amd", "csrc", f), "rb").read())
+        h.update(_normalised_source(os.path.join(ROOT, "raytracer-public_amd", "csrc", f)))
     return h.hexdigest()[:16]
 
 
