@@ -814,9 +814,10 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     // is resized or the tile list is rewritten under the queued frames.
     if (ctx->pending) {
         const ptk::RenderArgs& Q = ctx->pendingA;
-        const bool mega = p->mode == PT_MODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute && !stats;
-        const bool same = mega && Q.width == p->width && Q.height == p->height && Q.spp == p->spp && Q.max_bounces == p->max_bounces && Q.num_tris == p->num_tris &&
-                          ctx->pending_rank == p->tile_rank && ctx->pending_count == count && (Q.accum != nullptr) == (p->accumulate != 0);
+        const bool ref = p->mode == PT_MODE_REFERENCE;
+        const bool mega = (p->mode == PT_MODE_PATH || ref) && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute && !stats;
+        const bool same = mega && Q.width == p->width && Q.height == p->height && Q.ref_mode == (ref ? 1u : 0u) && (ref || (Q.spp == p->spp && Q.max_bounces == p->max_bounces)) &&
+                          Q.num_tris == p->num_tris && ctx->pending_rank == p->tile_rank && ctx->pending_count == count && (Q.accum != nullptr) == (!ref && p->accumulate != 0);
         if (!same) { if (int rc = flush_pending(ctx)) return rc; }
     }
 
@@ -875,7 +876,12 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     } else {
         ctx->accum_count = 0;
     }
-    const bool mega_path = p->mode == PT_MODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute;
+    // The persistent megakernel traces PT_MODE_PATH and PT_MODE_REFERENCE (one primary ray through each pixel centre + shade():
+    // its camera rays, traversal and sample / resolve machinery with spp = 1 and no bounces); PT_FLAG_SIMPLE_KERNEL selects the
+    // one-pixel-per-lane kernel for either.
+    const bool mega_ref = p->mode == PT_MODE_REFERENCE && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute;
+    const bool mega_path = (p->mode == PT_MODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute) || mega_ref;
+    if (mega_ref) { A.ref_mode = 1u; A.spp = 1u; A.max_bounces = 0u; }
     if (stats) {
         if (!mega_path) {      // the megakernel zeroes the block itself, on the stream its trace runs on (flush_pending_stats)
             if (int rc = flush_pending(ctx)) return rc;
@@ -888,7 +894,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     const bool ring = ctx->ring_used + 2 <= ctx->ring.size();
     hipEvent_t e0 = ring ? ctx->ring[ctx->ring_used] : ctx->ev_start, e1 = ring ? ctx->ring[ctx->ring_used + 1] : ctx->ev_stop;
     const int kmode = p->mode == PT_MODE_REFERENCE_PACKET ? PT_KMODE_PACKET : (p->mode == PT_MODE_REFERENCE ? PT_KMODE_REFERENCE : PT_KMODE_PATH);
-    if (kmode == PT_KMODE_PATH && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute) {
+    if (mega_path) {
         // ---- persistent megakernel: frames are queued and launched in batches of ctx->batch_size
         if (uint64_t(A.num_tiles) * A.spp * 64ull * ctx->batch_size > 0xFFFFFFFFull)      // item and sample indices are 32-bit
             return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: more than 2^32 pixel-samples per launch (lower spp, the resolution or pt_set_batch)");
@@ -899,7 +905,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         if (ctx->pending) {
             const ptk::RenderArgs& Q = ctx->pendingA;   // a frame joins the open batch only if it has the same shape and targets
             const bool same = Q.width == A.width && Q.height == A.height && Q.spp == A.spp && Q.max_bounces == A.max_bounces && Q.num_tris == A.num_tris &&
-                              Q.tiles == A.tiles && Q.num_tiles == A.num_tiles && Q.compact == A.compact && Q.accum == A.accum && !stats;
+                              Q.tiles == A.tiles && Q.num_tiles == A.num_tiles && Q.compact == A.compact && Q.accum == A.accum && Q.ref_mode == A.ref_mode && !stats;
             if (!same || ctx->pending >= PT_MAX_BATCH) { if (int rc = flush_pending(ctx)) return rc; }
         }
         if (!ctx->pending) { ctx->pendingA = A; ctx->pending_ring = false; ctx->pending_rank = p->tile_rank; ctx->pending_count = count; }

@@ -106,6 +106,7 @@ struct RenderArgs {
     const FrameParams* frames; float4* const* outs;     // device arrays of the frame slot, filled by launch_frame_params
     uint32_t  num_frames, batches_per_frame;
     uint32_t  prime;            // 1: launch_trace must zero the control block itself
+    uint32_t  ref_mode;         // 1: PT_MODE_REFERENCE on the megakernel -- one primary ray through each pixel centre, shade() of renderer.wgsl:348-353 (spp = 1, no bounces)
 };
 
 hipError_t launch_render(const RenderArgs& args, int kmode, bool stats, hipStream_t stream);

@@ -112,6 +112,26 @@ def test_reference_mode_single_ray_bit_exact(rt, orc, gpu_ctx, kind):
         assert same_bits(img, ref)
         for k in ("rays_closest", "nodes_examined", "tris_tested", "stack_drops", "max_stack", "samples"):
             assert st[k] == ost[k], k
+        # the reference's frame runs on the persistent megakernel by default (instrumented above); the uninstrumented build and
+        # the one-pixel-per-lane kernel (PT_FLAG_SIMPLE_KERNEL, counters included) give the same bits
+        p.flags = 0
+        gpu_ctx.render(p)
+        assert same_bits(gpu_ctx.read_radiance(), ref)
+        p.flags = rt.PT_FLAG_SIMPLE_KERNEL | rt.PT_FLAG_STATS
+        gpu_ctx.render(p)
+        assert same_bits(gpu_ctx.read_radiance(), ref)
+        st2 = gpu_ctx.stats()
+        for k in ("rays_closest", "nodes_examined", "tris_tested", "stack_drops", "max_stack", "samples"):
+            assert st2[k] == ost[k], k
+    # a batch of reference-mode frames with different cameras in one launch
+    gpu_ctx.set_batch(len(CAMS))
+    outs = []
+    for cam, quat in CAMS:
+        gpu_ctx.render(gpu_ctx.make_params(w, h, cam, quat, mode=rt.PT_MODE_REFERENCE))
+    gpu_ctx.set_batch(1)
+    last = gpu_ctx.read_radiance()
+    want, _, _ = orc.render(orc.make_params(w, h, tris.size // 9, CAMS[-1][0], CAMS[-1][1], mode=orc_mod.MODE_SINGLE), tris, bvh4)
+    assert same_bits(last, want)
 
 
 @pytest.mark.parametrize("kind", ["tetra", "soup", "dragon"])
