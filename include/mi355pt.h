@@ -73,7 +73,7 @@ typedef struct PtRenderParams {
 
 enum {
     PT_FLAG_STATS = 1u,          /* run the instrumented kernel variant and fill PtStats */
-    PT_FLAG_SIMPLE_KERNEL = 2u,  /* PT_MODE_PATH: one-pixel-per-lane kernel instead of the persistent megakernel (A/B checks) */
+    PT_FLAG_SIMPLE_KERNEL = 2u,  /* PT_MODE_PATH, PT_MODE_REFERENCE: one-pixel-per-lane kernel instead of the persistent megakernel (A/B checks) */
     PT_FLAG_BRUTE_FORCE = 4u,    /* modes 1, 2: ignore the BVH, test every triangle and every sphere of pt_set_spheres (config C1) */
     PT_FLAG_COMPACT = 8u         /* tile-major compact output (pt_compact_radiance / pt_set_compact_buffer) also when tile_count <= 1: the layout
                                     a one-member group gathers, so that one code path serves every group size */
