@@ -4,6 +4,7 @@ gather to rank 0, de-interleave -- with the CPU oracle standing in for the rende
 device-side equivalents (pt_render tile mode, pt_deinterleave) are covered bit-exactly on the
 GPU by tests/test_gpu_parity.py::test_tile_sharding_matches_whole_frame."""
 import importlib
+import importlib.util
 import os
 import socket
 import sys
@@ -77,3 +78,38 @@ def test_two_rank_gather_reassembles_the_frame(tmp_path, width, height):
     result = str(tmp_path / "ok.npy")
     mp.spawn(_worker, args=(2, port, width, height, result), nprocs=2, join=True)
     assert bool(np.load(result)[0])
+
+
+def _bench_module():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)           # only definitions run: the benchmark itself sits behind __main__
+    return mod
+
+
+@pytest.mark.parametrize("n_steps,batch,world", [(20, 20, 1), (256, 32, 1), (20, 20, 8), (256, 256, 8), (256, 64, 2), (7, 32, 4), (1, 1, 8)])
+def test_bench_launch_schedule_covers_every_step_once(n_steps, batch, world):
+    """bench.py's launches: every step in exactly one launch, in order, no launch larger than a batch; a sharded run's launches
+    shrink towards the end (its last gather is exposed), a single-GPU run uses full batches."""
+    bench = _bench_module()
+    launches = bench.schedule(n_steps, batch, world, False)
+    assert launches[0][0] == 0
+    done = 0
+    for first, nf in launches:
+        assert first == done and 1 <= nf <= batch
+        done += nf
+    assert done == n_steps
+    if world == 1:
+        assert all(nf == batch for _, nf in launches[:-1])
+    else:
+        sizes = [nf for _, nf in launches]
+        assert all(a >= b for a, b in zip(sizes, sizes[1:])) or sizes[-1] <= 8
+        assert sizes[-1] <= max(8, n_steps // 2)
+    assert bench.schedule(n_steps, batch, world, True) == [(i, min(batch, n_steps - i)) for i in range(0, n_steps, batch)]
+
+
+def test_bench_busy_time_is_the_union_of_launch_intervals():
+    bench = _bench_module()
+    assert bench.busy_ms([0.0, 10.0], [5.0, 5.0]) == pytest.approx(10.0)          # disjoint
+    assert bench.busy_ms([0.0, 2.0], [5.0, 5.0]) == pytest.approx(7.0)            # overlapping: never the sum of the spans
+    assert bench.busy_ms([0.0, 1.0, 20.0], [10.0, 2.0, 1.0]) == pytest.approx(11.0)   # contained + disjoint
