@@ -833,6 +833,27 @@ int orc_trace_ray(const float* tris, const uint32_t* bvh4, uint32_t numTris, con
     return h.hit ? 1 : 0;
 }
 
+// single-lane probes of the two intersection routines (pinned against the reference's own Python statement of the same
+// arithmetic, tests/test.py:64-99, by tests/test_ref_py_intersect.py)
+// intersectAABBPacketMask with one active lane, renderer.wgsl:121-169: returns the lane's hit flag, writes the box's tmin (INF on a miss)
+int orc_slab(const float o[3], const float inv[3], const float mn[3], const float mx[3], float best, float* tmin) {
+    Packet p; Mask m, out; float bestT[PACKET_SIZE];
+    for (int i = 0; i < PACKET_SIZE; i++) { p.origin[i] = v3(0, 0, 0); p.dir[i] = v3(0, 0, -1); p.invdir[i] = v3(INF_T, INF_T, INF_T); m.m[i] = false; bestT[i] = INF_T; }
+    p.origin[0] = v3(o[0], o[1], o[2]); p.invdir[0] = v3(inv[0], inv[1], inv[2]); m.m[0] = true; bestT[0] = best;
+    aabb_packet(p, v3(mn[0], mn[1], mn[2]), v3(mx[0], mx[1], mx[2]), m, bestT, out, *tmin);
+    return out.m[0] ? 1 : 0;
+}
+// intersectTrianglePacket with one active lane, renderer.wgsl:171-208: returns the hit flag, writes t (unchanged `best` on a miss)
+int orc_moller_trumbore(const float o[3], const float d[3], const float v0[3], const float v1[3], const float v2[3], float best, float* t) {
+    Packet p; Mask m; HitPacket h;
+    for (int i = 0; i < PACKET_SIZE; i++) { p.origin[i] = v3(0, 0, 0); p.dir[i] = v3(0, 0, -1); p.invdir[i] = v3(INF_T, INF_T, INF_T); m.m[i] = false; h.t[i] = best; h.hit[i] = false; h.tri[i] = INVALID; h.normal[i] = v3(0, 0, 0); }
+    p.origin[0] = v3(o[0], o[1], o[2]); p.dir[0] = v3(d[0], d[1], d[2]); m.m[0] = true;
+    tri_packet(p, v3(v0[0], v0[1], v0[2]), v3(v1[0], v1[1], v1[2]), v3(v2[0], v2[1], v2[2]), v3(0, 0, 1), 0u, m, h);
+    *t = h.t[0];
+    return h.hit[0] ? 1 : 0;
+}
+void orc_safe_inv_dir(const float d[3], float out[3]) { V3 r = safe_inv_dir(v3(d[0], d[1], d[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+
 float orc_rnd(uint32_t seed, uint32_t pixel, uint32_t sidx, uint32_t bounce, uint32_t dim) { return rnd(sample_key(seed, pixel, sidx), bounce, dim); }
 void orc_sincos_2pi(float u, float* c, float* s) { sincos_2pi(u, *c, *s); }
 void orc_cosine_dir(const float n[3], float u1, float u2, float out[3]) { V3 r = cosine_dir(v3(n[0], n[1], n[2]), u1, u2); out[0] = r.x; out[1] = r.y; out[2] = r.z; }

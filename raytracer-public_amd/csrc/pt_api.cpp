@@ -41,16 +41,16 @@ struct DevBuf {
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto,
-             flush = kAuto, passes = kAuto, slots = kAuto, cull = kAuto;
+             flush = kAuto, passes = kAuto, slots = kAuto, cull = kAuto, stats_batch = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"FLUSH", &PtTune::flush}, {"PASSES", &PtTune::passes}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}};
+            {"FILL", &PtTune::fill}, {"FLUSH", &PtTune::flush}, {"PASSES", &PtTune::passes}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "FLUSH", "PASSES", "SLOTS", "CULL"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "FLUSH", "PASSES", "SLOTS", "CULL", "STATSBATCH"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -440,7 +440,7 @@ int flush_pending(PtContext* ctx) {
     if (!ctx->pending) return PT_OK;
     const uint32_t count = ctx->tiles_count ? ctx->tiles_count : 1u;
     const bool sharded = ctx->pendingA.compact != 0u;
-    return flush_pending_stats(ctx, false, sharded, sharded ? count : 1u);
+    return flush_pending_stats(ctx, ctx->pendingA.stats != nullptr, sharded, sharded ? count : 1u);
 }
 
 } // namespace
@@ -815,7 +815,8 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     if (ctx->pending) {
         const ptk::RenderArgs& Q = ctx->pendingA;
         const bool ref = p->mode == PT_MODE_REFERENCE;
-        const bool mega = (p->mode == PT_MODE_PATH || ref) && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute && !stats;
+        const bool stats_joins = stats && PtTune::pick(ctx->tune.stats_batch, 0u) != 0u && Q.stats != nullptr;      // diagnostics: an instrumented multi-frame launch (tools/wave_timeline.py)
+        const bool mega = (p->mode == PT_MODE_PATH || ref) && !(p->flags & PT_FLAG_SIMPLE_KERNEL) && !brute && (!stats || stats_joins);
         const bool same = mega && Q.width == p->width && Q.height == p->height && Q.ref_mode == (ref ? 1u : 0u) && (ref || (Q.spp == p->spp && Q.max_bounces == p->max_bounces)) &&
                           Q.num_tris == p->num_tris && ctx->pending_rank == p->tile_rank && ctx->pending_count == count && (Q.accum != nullptr) == (!ref && p->accumulate != 0);
         if (!same) { if (int rc = flush_pending(ctx)) return rc; }
@@ -905,7 +906,8 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         if (ctx->pending) {
             const ptk::RenderArgs& Q = ctx->pendingA;   // a frame joins the open batch only if it has the same shape and targets
             const bool same = Q.width == A.width && Q.height == A.height && Q.spp == A.spp && Q.max_bounces == A.max_bounces && Q.num_tris == A.num_tris &&
-                              Q.tiles == A.tiles && Q.num_tiles == A.num_tiles && Q.compact == A.compact && Q.accum == A.accum && Q.ref_mode == A.ref_mode && !stats;
+                              Q.tiles == A.tiles && Q.num_tiles == A.num_tiles && Q.compact == A.compact && Q.accum == A.accum && Q.ref_mode == A.ref_mode && Q.stats == A.stats &&
+                              (!stats || PtTune::pick(ctx->tune.stats_batch, 0u) != 0u);
             if (!same || ctx->pending >= PT_MAX_BATCH) { if (int rc = flush_pending(ctx)) return rc; }
         }
         if (!ctx->pending) { ctx->pendingA = A; ctx->pending_ring = false; ctx->pending_rank = p->tile_rank; ctx->pending_count = count; }
@@ -913,7 +915,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         ctx->pending_frames.push_back(fp); ctx->pending_outs.push_back(A.out);
         ++ctx->pending;
         ctx->timed = false;
-        if (stats || ctx->pending >= ctx->batch_size) return flush_pending_stats(ctx, stats, sharded, count);
+        if ((stats && PtTune::pick(ctx->tune.stats_batch, 0u) == 0u) || ctx->pending >= ctx->batch_size) return flush_pending_stats(ctx, stats, sharded, count);
         return PT_OK;
     } else {
         if (int rc = flush_pending(ctx)) return rc;

@@ -64,6 +64,10 @@ class Oracle:
         L.orc_rnd.restype = C.c_float; L.orc_rnd.argtypes = [C.c_uint32] * 5
         L.orc_sincos_2pi.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_cosine_dir.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float)]
+        F3 = C.POINTER(C.c_float)
+        L.orc_slab.restype = C.c_int; L.orc_slab.argtypes = [F3, F3, F3, F3, C.c_float, F3]
+        L.orc_moller_trumbore.restype = C.c_int; L.orc_moller_trumbore.argtypes = [F3, F3, F3, F3, F3, C.c_float, F3]
+        L.orc_safe_inv_dir.argtypes = [F3, F3]
 
     # ---- scene build -------------------------------------------------
     def morton_sort(self, tris):
@@ -172,6 +176,26 @@ class Oracle:
         hit = self.lib.orc_trace_ray(_p(tris, C.c_float), _p(bvh4, C.c_uint32), C.c_uint32(tris.size // 9),
                                      _p(o, C.c_float), _p(d, C.c_float), C.c_int(int(anyhit)), C.byref(t), n, C.byref(tri))
         return bool(hit), t.value, np.array(list(n), np.float32), tri.value
+
+    # ---- single-lane probes of the intersection routines --------------
+    def slab(self, o, inv, mn, mx, best=1e30):
+        """intersectAABBPacketMask with one lane (renderer.wgsl:121-169) -> (hit, tmin)."""
+        a = [np.ascontiguousarray(v, np.float32) for v in (o, inv, mn, mx)]
+        t = C.c_float()
+        hit = self.lib.orc_slab(*[_p(v, C.c_float) for v in a], C.c_float(best), C.byref(t))
+        return bool(hit), np.float32(t.value)
+
+    def moller_trumbore(self, o, d, v0, v1, v2, best=1e30):
+        """intersectTrianglePacket with one lane (renderer.wgsl:171-208) -> (hit, t)."""
+        a = [np.ascontiguousarray(v, np.float32) for v in (o, d, v0, v1, v2)]
+        t = C.c_float()
+        hit = self.lib.orc_moller_trumbore(*[_p(v, C.c_float) for v in a], C.c_float(best), C.byref(t))
+        return bool(hit), np.float32(t.value)
+
+    def safe_inv_dir(self, d):
+        d = np.ascontiguousarray(d, np.float32); out = np.zeros(3, np.float32)
+        self.lib.orc_safe_inv_dir(_p(d, C.c_float), _p(out, C.c_float))
+        return out
 
     def tonemap(self, rgba, quantize=True):
         rgba = np.ascontiguousarray(rgba, np.float32)

@@ -10,8 +10,14 @@ tris = rt.procedural_scene(1, 262144) if sponza else rt.procedural_scene(0, 8714
 cam, quat = ((0.55, -0.05, 0.05), (0.0, 0.6630, 0.0, 0.7486)) if sponza else ((0, 0, 2.5), (0, 0, 0, 1))
 ctx = rt.Context(0); ctx.set_triangles(tris); ctx.build_bvh()
 p = ctx.make_params(1920, 1080, cam, quat, mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, stats=True)
-ctx.render(p); ctx.render(p)
-print("ms (stats build):", ctx.last_render_ms())
+B = int(os.environ.get("WT_BATCH", "1"))            # frames in the instrumented launch (diagnostics knob STATSBATCH)
+if B > 1:
+    rt.lib.pt_debug_set_tune(ctx.h, b"STATSBATCH", C.c_uint32(1)); ctx.set_batch(B)
+for rep in range(2):
+    for i in range(B):
+        p.frame = 100 * rep + i; ctx.render(p)
+    ctx.synchronize()
+print("frames in the launch: %d; ms (stats build): %.3f" % (B, ctx.last_render_ms()))
 buf = np.zeros((8192, 16), np.uint64); n = C.c_uint32()
 rt.lib.pt_debug_wave_times(ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_uint32(8192), C.byref(n))
 w = buf[: n.value].astype(np.float64)
@@ -33,5 +39,13 @@ tot = (w[:, 2] - w[:, 0]).sum() * 24.0   # 100 MHz ticks -> ~2.4 GHz cycles
 print('cycle shares of wave lifetime (s_memtime): shade %.1f%%, refill %.1f%%, traversal step %.1f%% (pre-exhaustion %.1f%%)' % tuple(100 * w[:, k].sum() / tot for k in (10, 11, 12, 13)))
 print('cycles per shade pass %.0f, per refill %.0f, per step pre %.0f, post %.0f' % (w[:, 10].sum() / w[:, 4].sum(), w[:, 11].sum() / w[:, 5].sum(), w[live, 13].sum() / pre_it.sum(), (w[live, 12] - w[live, 13]).sum() / post_it.sum()))
 st = ctx.stats(); print(st)
+order = np.argsort(end)[::-1][:12]
+print("slowest waves: end us | queue-empty us | iterations after | shade passes after | longest path that ended after (steps)")
+for k in order:
+    print("  %7.0f | %7.0f | %5d | %4d | %5d" % (end[k], qe[k], w[k, 3] - w[k, 6], w[k, 4] - w[k, 15], w[k, 14]))
+post = w[live, 3] - w[live, 6]
+print("iterations after queue-empty: p50 %d p90 %d p99 %d max %d; longest path ended after (steps): p50 %d p90 %d p99 %d max %d" %
+      (tuple(np.percentile(post, [50, 90, 99, 100])) + tuple(np.percentile(w[live, 14], [50, 90, 99, 100]))))
 dbg = np.zeros(16, np.uint64); rt.lib.pt_debug_counters(ctx.h, dbg.ctypes.data_as(C.c_void_p))
 print('pushes %d, at depth>=8 %.2f%%, >=12 %.2f%%, spilled(>=kShort) %.3f%%' % (dbg[8], 100.0 * dbg[9] / dbg[8], 100.0 * dbg[10] / dbg[8], 100.0 * dbg[11] / dbg[8]))
+print('longest path %d traversal steps, longest ray %d; paths >= 512 steps: %d, >= 1024: %d' % (dbg[12], dbg[13], dbg[14], dbg[15]))
