@@ -48,9 +48,10 @@ BYTES_NODE, BYTES_TRI, BYTES_SAMPLE = 32, 36, 16
 SIMDS, VALU_CYCLES_PER_WAVE_INST, CLOCK_HZ = 1024, 2.0, 2.4e9
 VALU_PEAK_GINST = SIMDS * CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST / 1e9
 L2_PEAK_GBS, L2_LINE, HBM_PEAK_GBS = 34500.0, 128, 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
 KERNEL_SOURCES = ["pt_megakernel.hip", "pt_device.h", "pt_kernels.h"]
 VERIFY_STEP = 16
+SHARD_PIECES = 4        # launches a sharded run is cut into at least (tools/shard_schedule_sim.py)
 
 
 def _normalised_source(path):
@@ -129,16 +130,47 @@ def cpu_baseline_node(tris, bvh4):
 
 
 def schedule(n_steps, batch, world, fixed_batch):
-    """[(first step, frames)] of the launches that cover n_steps.  A sharded run gathers launch b while launch b+1 traces, so its
-    LAST gather is exposed: its launches shrink towards the end (128, 64, 32, 16, 8, 8 for 256 steps on 8 GPUs)."""
+    """[(first step, frames)] of the launches that cover n_steps.
+
+    One GPU: full batches (a run of up to 32 frames of work is ONE launch: its sparse tail is paid once).
+    Sharded (world > 1): the gather of launch b travels while launch b+1 traces, and the LAST launch's gather and its drain are
+    exposed, so a run is cut into SHARD_PIECES launches of about equal size at least, never more than `batch` frames each, the last
+    ones no larger than the ones before -- chosen from the one-GPU replay of every rank's submission sequence
+    (tools/shard_schedule_sim.py -> profiles/r03_shard_schedule_sim.txt).  PT_BENCH_SCHEDULE="10,10" overrides (replays only)."""
+    forced = os.environ.get("PT_BENCH_SCHEDULE")
+    if forced and world > 1 and not fixed_batch:
+        sizes = [int(x) for x in forced.split(",") if x.strip()]
+        if sum(sizes) == n_steps and all(0 < x <= batch for x in sizes):
+            out, done = [], 0
+            for b in sizes:
+                out.append((done, b)); done += b
+            return out
     out, done = [], 0
+    if world > 1 and not fixed_batch:
+        pieces = max(SHARD_PIECES, -(-n_steps // batch))
+        pieces = max(1, min(pieces, n_steps))
+        base, extra = divmod(n_steps, pieces)
+        for i in range(pieces):                      # the larger pieces first
+            b = base + (1 if i < extra else 0)
+            out.append((done, b)); done += b
+        return out
     while done < n_steps:
-        left = n_steps - done
-        b = min(batch, left)
-        if world > 1 and not fixed_batch:
-            b = min(b, max(8, left // 2), left)
+        b = min(batch, n_steps - done)
         out.append((done, b)); done += b
     return out
+
+
+def submit_launches(ctx, p, launches, first_frame, batch, set_target, after_launch):
+    """The submission sequence of a run: for every launch its frames (pt_render with the target that is current), a pt_flush for a
+    partial batch, then `after_launch(k, nf)`.  bench.py and tools/shard_schedule_sim.py both submit through here."""
+    for k, (first, nf) in enumerate(launches):
+        for j in range(nf):
+            p.frame = first_frame + first + j
+            set_target(k, j, p.frame)
+            ctx.render(p)                # the library launches a full batch with its last frame ...
+        if nf < batch:
+            ctx.flush()                  # ... and a shorter one here (the slots stay sized for `batch` frames)
+        after_launch(k, nf)
 
 
 def busy_ms(starts, durs):
@@ -228,6 +260,8 @@ def main():
     # which overlap on the context's side streams.
     batch = int(os.environ.get("PT_BENCH_BATCH", "0")) or args.steps
     batch = max(1, min(32 * world, 256, batch))
+    if world > 1 and not fixed_batch:       # a sharded run is cut into pieces (schedule()): buffers and pt_set_batch are sized for the largest launch
+        batch = max([nf for _, nf in schedule(args.steps, batch, world, False)] + [nf for _, nf in schedule(max(args.warmup, 1), batch, world, False)])
     launch_log = []                  # (tag, frames) of every un-instrumented megakernel launch, in submission order
 
     ctx.set_batch(1)
@@ -236,6 +270,7 @@ def main():
         stride = max(rt.tile_layout(width, height, r, world)[1] for r in range(world))
         compact = [torch.zeros(batch, stride, dtype=torch.float32, device="cuda") for _ in range(2)]
         gathered = [torch.zeros(world, batch, stride, dtype=torch.float32, device="cuda") for _ in range(2)] if rank == 0 else [None, None]
+        frames_full = torch.zeros(batch, height * width * 4, dtype=torch.float32, device="cuda") if rank == 0 else None     # the de-interleaved frames of one launch
         host_stage = backend != "nccl"   # rehearsal path (gloo): stage through host memory
         torch.cuda.synchronize()         # the zero fills ran on torch's default stream; everything below uses the context's
         if not host_stage:               # bring the RCCL communicator up before anything is timed (even with --warmup 0)
@@ -274,8 +309,9 @@ def main():
         if rank == 0:
             if host_stage:
                 gathered[slot][:, :nf].copy_(torch.stack(work.cpu_list))
-            for j in range(nf):          # rank r's buffer of frame j sits at gathered[slot][r][j]
-                ctx.deinterleave(gathered[slot].data_ptr() + j * stride * 4, batch * stride, width, height, world)
+            # rank r's buffer of frame j sits at gathered[slot][r][j]: all nf frames are scattered by ONE launch, each into its own row-major frame
+            ctx.deinterleave_batch(gathered[slot].data_ptr(), batch * stride, stride, nf, width, height, world, frames_full.data_ptr(), height * width * 4)
+            last_frame["buf"] = nf - 1
 
     class _HostWork:                 # gloo rehearsal: synchronous host gather
         def __init__(self, buf):
@@ -297,20 +333,19 @@ def main():
         pending[0] = (work, slot, nf)
 
     def run(n_steps, first_frame, p, tag):    # called with `stream` current: n_steps frames as the launches of schedule()
-        for k, (first, nf) in enumerate(schedule(n_steps, batch, world, fixed_batch)):
-            for j in range(nf):
-                p.frame = first_frame + first + j
-                if sharded:
-                    ctx.set_compact_buffer(compact[k & 1][j].data_ptr(), stride)
-                else:
-                    ctx.set_output_buffer(frames_out[(k & 1) * batch + j].data_ptr(), height * width * 4)
-                    last_frame["index"], last_frame["buf"] = p.frame, (k & 1) * batch + j
-                ctx.render(p)                # the library launches a full batch with its last frame ...
-            if nf < batch:
-                ctx.flush()                  # ... and a shorter one here (the slots stay sized for `batch` frames)
+        def set_target(k, j, frame):
+            if sharded:
+                ctx.set_compact_buffer(compact[k & 1][j].data_ptr(), stride)
+            else:
+                ctx.set_output_buffer(frames_out[(k & 1) * batch + j].data_ptr(), height * width * 4)
+                last_frame["index"], last_frame["buf"] = frame, (k & 1) * batch + j
+
+        def after_launch(k, nf):
             launch_log.append((tag, nf))
             if sharded:
                 ship(k & 1, nf)
+
+        submit_launches(ctx, p, schedule(n_steps, batch, world, fixed_batch), first_frame, batch, set_target, after_launch)
         if sharded:
             finish(pending[0])
             pending[0] = None
@@ -344,7 +379,8 @@ def main():
         bvh4 = ctx.read_bvh4()
         with torch.cuda.stream(stream):
             if sharded:
-                got = ctx.read_radiance(width, height).copy()           # the last de-interleaved frame
+                ctx.synchronize()
+                got = frames_full[last_frame["buf"]].reshape(height, width, 4).cpu().numpy()     # the last de-interleaved frame
             else:
                 ctx.synchronize()
                 got = frames_out[last_frame["buf"]].reshape(height, width, 4).cpu().numpy()
@@ -410,13 +446,30 @@ def main():
                                  "command": pmc.get("command"), "frames_per_launch": pmc.get("frames_per_launch")})
             except Exception as e:       # a broken summary must not take the throughput line with it
                 pmc, pmc_info["error"] = None, str(e)
-        fractions, traffic, lane_util = {}, None, None
-        if pmc:
+        fractions, fractions_builder, traffic, lane_util = {}, {}, None, None
+        # The counters are only used when they describe THIS kernel build and THIS command: a stale summary (kernel sources edited since,
+        # another --steps / --warmup, another launch shape) yields "unmeasured" -- never a fraction of somebody else's counters.
+        pmc_usable = bool(pmc) and not pmc_info.get("stale") and abs(float(pmc.get("frames_per_launch") or 0) - frames_per_launch) < 1e-9 and \
+            ("--steps %d " % args.steps) in (str(pmc.get("command")) + " ") and ("--warmup %d " % args.warmup) in (str(pmc.get("command")) + " ")
+        pmc_info["used"] = pmc_usable
+        if pmc and not pmc_usable:
+            pmc_info["why_unused"] = "source_tag differs (kernel edited since the passes: re-run tools/pmc_bench.sh)" if pmc_info.get("stale") else "the passes were taken over another command / launch shape"
+        if pmc_usable:
             c = pmc["per_frame"]
             s = busy_per_frame * 1e-3
-            fractions["valu_issue"] = c["SQ_INSTS_VALU"] / s / 1e9 / VALU_PEAK_GINST
-            fractions["l2_bandwidth"] = (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE / s / 1e9 / L2_PEAK_GBS
-            fractions["hbm_fabric"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / s / 1e9 / HBM_PEAK_GBS
+
+            def fracs(sec):
+                return {"valu_issue": c["SQ_INSTS_VALU"] / sec / 1e9 / VALU_PEAK_GINST,
+                        "l2_bandwidth": (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE / sec / 1e9 / L2_PEAK_GBS,
+                        "hbm_fabric": (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / sec / 1e9 / HBM_PEAK_GBS}
+
+            fractions = fracs(s)
+            # the same counters over the kernel time of the session they were taken in (tools/pmc_bench.sh stores it): a 10 % difference
+            # between that box and this one shows up as a difference between the two sets instead of hiding in `frac`
+            bms = pmc.get("builder_kernel_busy_ms_per_frame")
+            if bms:
+                fractions_builder = fracs(float(bms) * 1e-3)
+                pmc_info["builder_kernel_busy_ms_per_frame"] = bms
             lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
             traffic = int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 * frames_per_launch)
             bound = max(fractions, key=fractions.get)
@@ -431,11 +484,14 @@ def main():
             "kernel": "trace_paths_kernel<false,false> (persistent megakernel)",
             "kernel_busy_ms": round(busy, 4), "kernel_busy_ms_per_frame": round(busy_per_frame, 5), "launches": int(len(k_ms)),
             "kernel_avg_launch_ms": round(float(np.mean(k_ms)), 4) if len(k_ms) else None, "frames_per_launch": frames_per_launch,
-            "fractions": {k: round(v, 5) for k, v in fractions.items()}, "lane_utilisation": None if lane_util is None else round(lane_util, 4),
+            "fractions": {k: round(v, 5) for k, v in fractions.items()},
+            "fractions_over_builder_time": {k: round(v, 5) for k, v in fractions_builder.items()},
+            "lane_utilisation": None if lane_util is None else round(lane_util, 4),
             "pmc": pmc_info,
             "definition": "frac = (per-frame counter total of the timed launches, rocprofv3 --pmc of this command, profiles/) / (kernel busy time per frame, hipEvents of this run) / peak; "
                           "valu_issue: SQ_INSTS_VALU x 2 cycles over 1024 SIMDs x 2.4 GHz; l2_bandwidth: (TCC_HIT+TCC_MISS) x 128 B over 34.5 TB/s; "
-                          "hbm_fabric: (FETCH_SIZE+WRITE_SIZE) x 1024 over 8 TB/s (FETCH_SIZE includes Infinity-Cache hits); bound = the largest",
+                          "hbm_fabric: (FETCH_SIZE+WRITE_SIZE) x 1024 over 8 TB/s (FETCH_SIZE includes Infinity-Cache hits); bound = the largest; fractions_over_builder_time = the same "
+                          "counters over the kernel time of the session the counters were taken in (another box: the two sets differ by the boxes' speed difference)",
             "algorithmic": {"GBps": round(algorithmic_gbs, 2), "bytes_per_frame": int(my_bytes), "bytes_per_frame_min_max": [int(min(frame_bytes)), int(max(frame_bytes))],
                             "over_hbm_peak": round(algorithmic_gbs / HBM_PEAK_GBS, 4),
                             "note": "SURVEY 8d: 32 B x node records examined + 36 B x triangles tested + 16 B x samples, over the kernel busy time; the working set (67 MB) is "

@@ -193,6 +193,11 @@ int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t ds
 /* Number of 8x8 tiles / pixels-slots this rank owns for a W x H frame split tile_count ways. */
 int pt_tile_layout(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count,
                    uint32_t* num_tiles, uint64_t* compact_floats);
+/* The tile ids (ty * ceil(W/8) + tx) this rank owns, in the order of its compact buffer: slot s of the buffer holds tile ids[s]
+ * (64 pixels, row-major inside the 8x8 tile).  ids may be NULL to ask for the count only; capacity in entries.  This is the list
+ * pt_render uploads for the share -- callers that assemble or check compact buffers themselves take the order from here. */
+int pt_tile_ids(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count,
+                uint32_t* ids, uint32_t capacity, uint32_t* num_tiles);
 /* Device pointer + size of this rank's compact radiance buffer (tile-major, 64 px per tile,
  * f32 RGBA) after a render with tile_count > 1: the send buffer of the RCCL gather. */
 int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats);
@@ -201,19 +206,32 @@ int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats);
  * `floats` is the buffer's capacity.  The buffer that is current when a frame is submitted is that frame's
  * target, also for frames still queued by pt_set_batch when the target changes.  Lifetime rule: a buffer
  * handed in here must stay allocated until a pt_synchronize (or any read-back) issued after the last frame
- * that was submitted while it was current has returned.  device_ptr = NULL restores the internal buffer and
- * launches whatever is still queued for caller-owned targets (it does not wait for it). */
+ * that was submitted while it was current has returned -- or until pt_buffer_busy says it is free.  device_ptr = NULL
+ * restores the internal buffer, launches whatever is still queued for caller-owned targets AND waits for it: when the call
+ * returns no frame targets a caller-owned buffer any more. */
 int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
 /* The same for whole frames (tile_count <= 1): render into a caller-owned row-major f32 RGBA device buffer of at least
  * width*height*4 floats instead of the context's own frame buffer, e.g. one buffer per frame of a batched launch so that
  * every frame stays available (frames of one launch that share a target leave only the last one's result, exactly as if they
  * had been rendered one after the other).  The read-backs read the target of the last frame.  Same lifetime rule as
- * pt_set_compact_buffer; NULL restores the internal buffer and launches what is still queued. */
+ * pt_set_compact_buffer; NULL restores the internal buffer, launches what is still queued and waits for it. */
 int pt_set_output_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
+/* *busy = 1 while a frame that is queued (pt_set_batch) or in flight (launched, not yet resolved) still targets an address inside
+ * [device_ptr, device_ptr + bytes): the check to make before freeing or re-using a buffer that was handed to
+ * pt_set_compact_buffer / pt_set_output_buffer.  Does not wait. */
+int pt_buffer_busy(PtContext* ctx, const void* device_ptr, uint64_t bytes, int* busy);
 /* Rank 0: scatter `tile_count` gathered compact buffers (device memory, concatenated in rank
  * order, each padded to `stride_floats`) into the context's full-frame radiance buffer. */
 int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride_floats,
                     uint32_t width, uint32_t height, uint32_t tile_count);
+/* The same for a gathered BATCH of frames in one launch: rank r's share of frame j sits at gathered + r * rank_stride_floats +
+ * j * frame_stride_floats (what one gather of `num_frames` consecutive compact buffers per rank leaves on the root); frame j is
+ * scattered to frames_out_device + j * out_stride_floats (row-major f32 RGBA, caller-owned).  frames_out_device = NULL: the
+ * context's own frame buffer, which holds one frame -- only the last frame of the batch is scattered (the earlier ones would
+ * be replaced by it).  The read-backs then read the last frame. */
+int pt_deinterleave_batch(PtContext* ctx, const void* gathered_device, uint64_t rank_stride_floats, uint64_t frame_stride_floats,
+                          uint32_t num_frames, uint32_t width, uint32_t height, uint32_t tile_count,
+                          void* frames_out_device, uint64_t out_stride_floats);
 
 /* ---- one image from all GPUs of the node: a group of contexts inside ONE process ------------------------------
  *

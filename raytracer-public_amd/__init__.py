@@ -55,14 +55,14 @@ class PtStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
-# every symbol include/mi355pt.h declares (tests/test_abi.py checks the header against this)
+# every symbol include/mi355pt.h declares (tests/test_host_build.py::test_library_exports_every_declared_symbol checks the header against this)
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_version", "pt_set_stream", "pt_get_stream", "pt_synchronize",
     "pt_compute_bvh2_sizing", "pt_compute_bvh4_sizing", "pt_morton_sort", "pt_collapse_lbvh2_to_bvh4",
     "pt_bvh2_to_bvh4_wide", "pt_file_write_u32", "pt_file_read_u32", "pt_scene_procedural",
     "pt_set_triangles", "pt_build_bvh", "pt_build_lbvh2", "pt_read_bvh2", "pt_set_bvh4", "pt_set_bvh2",
     "pt_read_bvh4", "pt_set_spheres", "pt_scene_info", "pt_render", "pt_last_render_ms", "pt_set_batch", "pt_flush", "pt_timing_begin", "pt_timing_collect", "pt_timing_collect_spans", "pt_set_compact_buffer", "pt_set_output_buffer", "pt_get_stats", "pt_read_radiance",
-    "pt_read_rgba8", "pt_read_tonemapped", "pt_tile_layout", "pt_compact_radiance", "pt_deinterleave",
+    "pt_read_rgba8", "pt_read_tonemapped", "pt_tile_layout", "pt_tile_ids", "pt_compact_radiance", "pt_deinterleave", "pt_deinterleave_batch", "pt_buffer_busy",
     "pt_group_create", "pt_group_destroy", "pt_group_last_error", "pt_group_size", "pt_group_context", "pt_group_set_triangles", "pt_group_build_bvh",
     "pt_group_set_bvh2", "pt_group_set_bvh4", "pt_group_set_batch", "pt_group_render", "pt_group_flush", "pt_group_synchronize", "pt_group_read_radiance",
     "pt_group_read_rgba8", "pt_group_read_tonemapped",
@@ -166,6 +166,15 @@ def tile_layout(width, height, rank, count):
     nt, fl = C.c_uint32(), C.c_uint64()
     _check(lib.pt_tile_layout(C.c_uint32(width), C.c_uint32(height), C.c_uint32(rank), C.c_uint32(count), C.byref(nt), C.byref(fl)))
     return nt.value, fl.value
+
+
+def tile_ids(width, height, rank, count):
+    """Tile ids (ty * ceil(W/8) + tx) of the rank's share, in compact-buffer order."""
+    n = C.c_uint32()
+    _check(lib.pt_tile_ids(C.c_uint32(width), C.c_uint32(height), C.c_uint32(rank), C.c_uint32(count), None, C.c_uint32(0), C.byref(n)))
+    ids = np.zeros(max(n.value, 1), np.uint32)
+    _check(lib.pt_tile_ids(C.c_uint32(width), C.c_uint32(height), C.c_uint32(rank), C.c_uint32(count), ids.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(ids.size), C.byref(n)))
+    return ids[: n.value]
 
 
 # ---- device context -----------------------------------------------------------------------
@@ -327,6 +336,16 @@ class Context:
         self._ck(lib.pt_deinterleave(self.h, C.c_void_p(gathered_device_ptr), C.c_uint64(stride_floats),
                                      C.c_uint32(width), C.c_uint32(height), C.c_uint32(tile_count)))
         self._last = (width, height)
+
+    def deinterleave_batch(self, gathered_device_ptr, rank_stride_floats, frame_stride_floats, num_frames, width, height, tile_count, frames_out_ptr=0, out_stride_floats=0):
+        self._ck(lib.pt_deinterleave_batch(self.h, C.c_void_p(gathered_device_ptr), C.c_uint64(rank_stride_floats), C.c_uint64(frame_stride_floats), C.c_uint32(num_frames),
+                                           C.c_uint32(width), C.c_uint32(height), C.c_uint32(tile_count), C.c_void_p(frames_out_ptr or None), C.c_uint64(out_stride_floats)))
+        self._last = (width, height)
+
+    def buffer_busy(self, device_ptr, nbytes):
+        b = C.c_int()
+        self._ck(lib.pt_buffer_busy(self.h, C.c_void_p(device_ptr), C.c_uint64(nbytes), C.byref(b)))
+        return bool(b.value)
 
 
 PT_GROUP_TRANSPORT_RCCL, PT_GROUP_TRANSPORT_COPY = 0, 1

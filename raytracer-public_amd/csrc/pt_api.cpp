@@ -102,6 +102,7 @@ struct PtContext {
         uint32_t cull_key[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t num_trace_tiles = 0; bool cull_valid = false;
         DevBuf<ptk::FrameParams> frame_params; DevBuf<float4*> frame_outs;      // per-frame parameters / targets of the launch in this slot
         const void* primed_ptr = nullptr; size_t primed_samples = 0;   // what the resident prefill covers
+        std::vector<float4*> launched_outs;                             // output targets of the launch last placed in this slot (pt_buffer_busy)
     };
     static constexpr int kMaxSlots = 16;
     FrameSlot slots[kMaxSlots]; int num_slots = 0; uint32_t next_slot = 0;
@@ -115,6 +116,7 @@ struct PtContext {
     uint32_t out_w = 0, out_h = 0;   // dimensions of the last full-frame result in d_out
     uint32_t accum_w = 0, accum_h = 0, accum_count = 0, accum_rank = 0;
     uint64_t compact_floats = 0;
+    uint32_t share_w = 0, share_h = 0, share_count = 0, share_max_tiles = 0;      // cached: largest tile share of a (W, H, count) split (pt_deinterleave*)
     float4* ext_compact = nullptr; uint64_t ext_compact_floats = 0;
     float4* ext_out = nullptr; uint64_t ext_out_floats = 0;      // caller-owned whole-frame target (pt_set_output_buffer)
     const float4* last_full = nullptr;                          // where the last whole-frame result lives (d_out or a caller's buffer)
@@ -187,13 +189,16 @@ int upload_wide(PtContext* ctx, const uint32_t* bvh4, uint64_t words) {
 // Tiles whose every camera ray provably misses the root box need no tracing: their samples keep the primed miss value.  The
 // rectangle is the bounding box of the eight projected corners of the root's (f16, exactly representable) bounds, in tile
 // units, widened by a margin of two pixels -- orders of magnitude more than the rounding of the ray set-up (renderer.wgsl:387-395)
-// can move a ray.  No culling when a corner is beside or behind the eye, or when the quaternion is not of unit length (the
-// reference's rotateVectorByQuat is a rotation only then).  Returns false for "trace everything".
+// can move a ray.  No culling when a corner is beside or behind the eye, or when the quaternion is not of unit length to within
+// 1e-5 (the reference's rotateVectorByQuat is a rotation only then).  Returns false for "trace everything".
 struct TileRect { uint32_t tx0, ty0, tx1, ty1; };     // half-open, in tiles
 bool root_box_rect(const pt::WideBvh& w, const ptk::FrameParams& f, uint32_t width, uint32_t height, TileRect& out) {
     const double qx = f.quat[0], qy = f.quat[1], qz = f.quat[2], qw = f.quat[3];
     const double qn = qx * qx + qy * qy + qz * qz + qw * qw;
-    if (!(qn > 0.999 && qn < 1.001) || !(f.focal > 1e-3f) || !(f.aspect > 1e-3f)) return false;
+    // |q|^2 within 1e-5 of 1 (an f32-normalised quaternion passes): for a longer or shorter q the reference's rotateVectorByQuat
+    // scales and shears the direction by about |q|^2 - 1, i.e. up to that times half the image width in pixels at the screen edge --
+    // 1e-5 x 16384 px stays far inside the two-pixel margin below; anything sloppier traces every tile
+    if (!(qn > 1.0 - 1e-5 && qn < 1.0 + 1e-5) || !(f.focal > 1e-3f) || !(f.aspect > 1e-3f)) return false;
     const double mn[3] = {pt::half_to_float(w.root_box[0] & 0xffffu), pt::half_to_float(w.root_box[0] >> 16), pt::half_to_float(w.root_box[1] & 0xffffu)};
     const double mx[3] = {pt::half_to_float(w.root_box[1] >> 16), pt::half_to_float(w.root_box[2] & 0xffffu), pt::half_to_float(w.root_box[2] >> 16)};
     double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
@@ -293,7 +298,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     // multiple or a divisor of the frame count keep the frames of a launch aligned: all rows are at the same image position at
     // the same time, so the frames share the BVH nodes they pull through L2.  Long launches take one row per frame (few places
     // in flight = locality); short launches cut every frame into 128 segments (fine interleave of object and background tiles
-    // = balance when each wavefront only sees a few chunks).  Measured: tools/sweeps/tune20.sh .. tune22.sh.
+    // = balance when each wavefront only sees a few chunks).  Measured: tools/sweep.sh ROWS.
     {
         const uint32_t work8_r = nf * 8u / (count ? count : 1u);
         A.perm_rows = PtTune::pick(ctx->tune.rows, work8_r >= 64u ? nf : (work8_r >= 8u ? 128u * nf : 64u * nf));
@@ -314,7 +319,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: launch too large for the 32-bit work-queue cursor (more than 2^32 - grid * chunk items; lower spp, the resolution or the batch)");
     }
     {   // XCD-aware queue for long launches: 8 ranges of the logical item order, one cursor per XCD (chunk aligned; 0 = one queue).
-        // Measured (tools/sweeps/tune17.sh, tools/sweeps/tune18.sh): 32-frame launches +2..3.5 %, HBM fetch traffic halved (L2 hit rate 85 -> 91 %);
+        // Measured (tools/sweep.sh XCD): 32-frame launches +2..3.5 %, HBM fetch traffic halved (L2 hit rate 85 -> 91 %);
         // no gain at 8 frames of work, a loss for a single frame (the ranges are not equally heavy).
         const uint32_t per = (A.total_items + 7u) / 8u;
         const uint32_t work8_q = nf * 8u / (count ? count : 1u);
@@ -326,7 +331,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
     // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
     // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small
-    // sharded launches need several in flight to fill the chip.  Measured: tools/sweeps/tune13.sh, tools/sweeps/tune14.sh.
+    // sharded launches need several in flight to fill the chip.  Measured: tools/sweep.sh SLOTS, tools/pipe_sweep.sh.
     auto slots_for = [&](uint32_t frames) {
         const uint32_t w8 = frames * 8u / (count ? count : 1u);      // eighths of a whole frame
         int n = int(PtTune::pick(ctx->tune.slots, w8 >= 256u ? 3u : (w8 >= 64u ? 4u : (w8 >= 16u ? PT_FRAME_SLOTS : (w8 >= 8u ? (sharded ? 4u : 6u) : (sharded ? 8u : PT_FRAME_SLOTS))))));
@@ -360,7 +365,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         PT_HIP(ctx, s.frame_params.ensure(std::max<size_t>(ctx->batch_size, nf))); PT_HIP(ctx, s.frame_outs.ensure(std::max<size_t>(ctx->batch_size, nf)));
         if (s.primed_ptr != (const void*)s.samples.ptr || s.primed_samples < cap_samples) {
             if (s.used) PT_HIP(ctx, hipStreamWaitEvent(s.side, s.resolved, 0));
-            PT_HIP(ctx, ptk::launch_prime(s.queue.ptr, s.samples.ptr, uint32_t(cap_samples), s.side));
+            PT_HIP(ctx, ptk::launch_prime(s.queue.ptr, s.side));
             s.primed_ptr = s.samples.ptr; s.primed_samples = cap_samples;
         }
     }
@@ -422,6 +427,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
             F[i].accum_mode = (F[i].accum_mode & 0xffu) | (superseded ? 0x100u : 0u);
         }
         PT_HIP(ctx, ptk::launch_frame_params(F.data(), ctx->pending_outs.data(), nf, sl.frame_params.ptr, sl.frame_outs.ptr, sl.side));
+        sl.launched_outs.assign(ctx->pending_outs.begin(), ctx->pending_outs.begin() + nf);
         A.frames = sl.frame_params.ptr; A.outs = sl.frame_outs.ptr;
     }
     // timing ring: events tightly around the trace kernels on the stream they run on
@@ -786,9 +792,21 @@ int pt_scene_info(PtContext* ctx, uint32_t* num_tris, uint32_t* num_nodes2, uint
 int pt_tile_layout(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count, uint32_t* num_tiles, uint64_t* compact_floats) {
     if (tile_count == 0) tile_count = 1;
     if (tile_rank >= tile_count) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_tile_layout: rank >= count");
-    std::vector<uint32_t> t; pt::tile_list(width, height, tile_rank, tile_count, t);
+    const uint32_t n = pt::tile_count_of(width, height, tile_rank, tile_count);      // closed form: no list is built
+    if (num_tiles) *num_tiles = n;
+    if (compact_floats) *compact_floats = uint64_t(n) * 64ull * 4ull;
+    return PT_OK;
+}
+
+int pt_tile_ids(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count, uint32_t* ids, uint32_t capacity, uint32_t* num_tiles) {
+    if (tile_count == 0) tile_count = 1;
+    if (tile_rank >= tile_count) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_tile_ids: rank >= count");
+    std::vector<uint32_t> t; pt::tile_list(width, height, tile_rank, tile_count, t);      // the list pt_render uploads for this share
     if (num_tiles) *num_tiles = uint32_t(t.size());
-    if (compact_floats) *compact_floats = uint64_t(t.size()) * 64ull * 4ull;
+    if (ids) {
+        if (capacity < t.size()) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_tile_ids: destination too small");
+        if (!t.empty()) std::memcpy(ids, t.data(), t.size() * sizeof(uint32_t));
+    }
     return PT_OK;
 }
 
@@ -1067,7 +1085,10 @@ int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t ds
 
 int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats) {
     if (int rc = bind(ctx)) return rc;
-    if (!device_ptr) { if (int rc = flush_pending(ctx)) return rc; }    // frames queued for the caller's buffers are launched before the caller is told "no longer yours to keep"
+    if (!device_ptr) {       // "no longer yours to keep": everything queued or in flight for the caller's buffers has been delivered when this returns
+        if (int rc = flush_pending(ctx)) return rc;
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->ext_compact = (float4*)device_ptr;
     ctx->ext_compact_floats = device_ptr ? floats : 0;
     return PT_OK;
@@ -1075,7 +1096,10 @@ int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats) {
 
 int pt_set_output_buffer(PtContext* ctx, void* device_ptr, uint64_t floats) {
     if (int rc = bind(ctx)) return rc;
-    if (!device_ptr) { if (int rc = flush_pending(ctx)) return rc; }
+    if (!device_ptr) {
+        if (int rc = flush_pending(ctx)) return rc;
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->ext_out = (float4*)device_ptr;
     ctx->ext_out_floats = device_ptr ? floats : 0;
     return PT_OK;
@@ -1090,18 +1114,61 @@ int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats) {
     return PT_OK;
 }
 
-int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride_floats, uint32_t width, uint32_t height, uint32_t tile_count) {
+// largest share of a W x H frame split `count` ways, in tiles: cached per context (the group / bench call this once per batch)
+static uint32_t max_share_tiles(PtContext* ctx, uint32_t width, uint32_t height, uint32_t count) {
+    if (ctx->share_w != width || ctx->share_h != height || ctx->share_count != count) {
+        uint32_t m = 0;
+        for (uint32_t r = 0; r < count; ++r) m = std::max(m, pt::tile_count_of(width, height, r, count));
+        ctx->share_w = width; ctx->share_h = height; ctx->share_count = count; ctx->share_max_tiles = m;
+    }
+    return ctx->share_max_tiles;
+}
+
+int pt_deinterleave_batch(PtContext* ctx, const void* gathered_device, uint64_t rank_stride_floats, uint64_t frame_stride_floats, uint32_t num_frames,
+                          uint32_t width, uint32_t height, uint32_t tile_count, void* frames_out_device, uint64_t out_stride_floats) {
     if (int rc = bind(ctx)) return rc;
     if (int rc = flush_pending(ctx)) return rc;
-    if (!gathered_device || tile_count == 0 || (stride_floats & 3)) return fail(ctx, PT_ERR_INVALID_ARG, "pt_deinterleave: bad arguments");
-    for (uint32_t r = 0; r < tile_count; ++r) {
-        uint32_t nt = 0; pt_tile_layout(width, height, r, tile_count, &nt, nullptr);
-        if (uint64_t(nt) * 256ull > stride_floats) return fail(ctx, PT_ERR_INVALID_ARG, "pt_deinterleave: stride smaller than a rank's compact buffer");
-    }
+    if (!gathered_device || tile_count == 0 || num_frames == 0 || (rank_stride_floats & 3) || (frame_stride_floats & 3) || (out_stride_floats & 3) || width == 0 || height == 0)
+        return fail(ctx, PT_ERR_INVALID_ARG, "pt_deinterleave_batch: bad arguments");
+    const uint64_t share = uint64_t(max_share_tiles(ctx, width, height, tile_count)) * 256ull;
+    if (share > frame_stride_floats && num_frames > 1u) return fail(ctx, PT_ERR_INVALID_ARG, "pt_deinterleave_batch: frame stride smaller than a rank's compact buffer");
+    if (share + uint64_t(num_frames - 1u) * frame_stride_floats > rank_stride_floats) return fail(ctx, PT_ERR_INVALID_ARG, "pt_deinterleave_batch: rank stride smaller than the frames of one rank");
     const size_t npx = size_t(width) * height;
-    PT_HIP(ctx, ctx->d_out.ensure(npx));
-    PT_HIP(ctx, ptk::launch_deinterleave((const float4*)gathered_device, stride_floats / 4, ctx->d_out.ptr, width, height, tile_count, ctx->stream));
-    ctx->out_w = width; ctx->out_h = height; ctx->last_full = ctx->d_out.ptr;
+    float4* out = (float4*)frames_out_device; uint64_t out_stride_px = out_stride_floats / 4u;
+    if (out) {
+        if (num_frames > 1u && out_stride_px < npx) return fail(ctx, PT_ERR_INVALID_ARG, "pt_deinterleave_batch: output stride smaller than a frame");
+    } else {
+        // the context's own frame buffer holds ONE frame: earlier frames of the batch are delivered and replaced (frames of one launch that
+        // share a target leave the last one's result, as with pt_render); only the last one is scattered
+        PT_HIP(ctx, ctx->d_out.ensure(npx));
+        out = ctx->d_out.ptr; out_stride_px = 0;
+        gathered_device = (const char*)gathered_device + size_t(num_frames - 1u) * frame_stride_floats * sizeof(float);
+        num_frames = 1u;
+    }
+    PT_HIP(ctx, ptk::launch_deinterleave((const float4*)gathered_device, rank_stride_floats / 4u, frame_stride_floats / 4u, num_frames, out, out_stride_px,
+                                         width, height, tile_count, ctx->stream));
+    ctx->out_w = width; ctx->out_h = height; ctx->last_full = out + size_t(num_frames - 1u) * out_stride_px;
+    return PT_OK;
+}
+
+int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride_floats, uint32_t width, uint32_t height, uint32_t tile_count) {
+    return pt_deinterleave_batch(ctx, gathered_device, stride_floats, 0, 1, width, height, tile_count, nullptr, 0);
+}
+
+int pt_buffer_busy(PtContext* ctx, const void* device_ptr, uint64_t bytes, int* busy) {
+    if (int rc = bind(ctx)) return rc;
+    if (!busy) return fail(ctx, PT_ERR_INVALID_ARG, "pt_buffer_busy: null output");
+    const char* lo = (const char*)device_ptr; const char* hi = lo + bytes;
+    auto in_range = [&](const float4* t) { return device_ptr && (const char*)t >= lo && (const char*)t < hi; };
+    *busy = 0;
+    for (uint32_t i = 0; i < ctx->pending && !*busy; ++i) if (in_range(ctx->pending_outs[i])) *busy = 1;        // queued, not launched yet
+    for (const auto& sl : ctx->slots) {
+        if (*busy || !sl.side || !sl.used || sl.launched_outs.empty()) continue;
+        const hipError_t q = hipEventQuery(sl.resolved);
+        (void)hipGetLastError();
+        if (q != hipErrorNotReady) continue;                                                                     // that launch has delivered its frames
+        for (const float4* t : sl.launched_outs) if (in_range(t)) { *busy = 1; break; }
+    }
     return PT_OK;
 }
 

@@ -67,8 +67,10 @@ struct PtGroup {
     uint64_t stride = 0;                          // floats per frame and rank (the largest share)
     std::vector<float*> compact[2];               // [set][rank]: batch * stride floats on that rank's GPU
     float* gathered[2] = {nullptr, nullptr};      // rank 0's GPU: n * batch * stride floats
-    hipEvent_t copied[2] = {nullptr, nullptr};    // copy transport: all shares of the set have arrived on rank 0
-    std::vector<hipEvent_t> ready;                // copy transport: member r's batch is resolved
+    hipEvent_t consumed[2] = {nullptr, nullptr};  // copy transport: rank 0 has de-interleaved what was last copied into gathered[set] (the peers' next copy into it waits for this)
+    bool consumed_valid[2] = {false, false};
+    std::vector<hipEvent_t> ready;                // copy transport: member r's share of the batch has arrived on rank 0
+    float* frames_out = nullptr; uint64_t frames_out_cap = 0;   // rank 0: the de-interleaved frames of a batch (batch * W * H * 4 floats), scattered by ONE launch
     uint32_t set = 0, queued = 0;                 // current buffer set, frames submitted into it
     bool accumulating = false, dirty = false;     // an accumulating sequence gathers only when an image is asked for
     bool have_frame = false;
@@ -90,7 +92,9 @@ void free_buffers(PtGroup* g) {
             if (g->compact[s][r]) { (void)hipSetDevice(g->devices[r]); (void)hipFree(g->compact[s][r]); }
         g->compact[s].clear();
         if (g->gathered[s]) { (void)hipSetDevice(g->devices[0]); (void)hipFree(g->gathered[s]); g->gathered[s] = nullptr; }
+        g->consumed_valid[s] = false;
     }
+    if (g->frames_out) { (void)hipSetDevice(g->devices[0]); (void)hipFree(g->frames_out); g->frames_out = nullptr; g->frames_out_cap = 0; }
 }
 
 // (re)allocate the compact / gathered buffers for a frame shape; drains what is in flight first
@@ -117,17 +121,24 @@ int ensure_buffers(PtGroup* g, uint32_t width, uint32_t height) {
         G_HIP(g, hipSetDevice(g->devices[0]));
         G_HIP(g, hipMalloc((void**)&g->gathered[s], bytes * g->n));
     }
+    if (g->batch > 1u) {          // every frame of a batch is delivered: one row-major frame each on rank 0 (a batch of 1 lands in the context's own frame buffer)
+        G_HIP(g, hipSetDevice(g->devices[0]));
+        g->frames_out_cap = uint64_t(g->batch) * width * height * 4ull;
+        G_HIP(g, hipMalloc((void**)&g->frames_out, g->frames_out_cap * sizeof(float)));
+    }
     g->set = 0; g->queued = 0;
     return PT_OK;
 }
 
-// Gather the `frames` frames submitted into buffer set `s` on rank 0 and de-interleave them (the last one stays the result).
+// Gather the `frames` frames submitted into buffer set `s` on rank 0 and de-interleave them with one launch (the last one stays the result
+// the read-backs see).  Only the frames that were submitted travel: rank r's share of frame j lands at gathered[s] + (r * frames + j) * stride.
 int gather_set(PtGroup* g, uint32_t s, uint32_t frames) {
     if (frames == 0) return PT_OK;
     for (uint32_t r = 0; r < g->n; ++r) G_PT(g, r, pt_flush(g->ctx[r]));          // a partly filled batch is launched now
-    const size_t count = size_t(g->batch) * g->stride;                            // floats per rank (whole set: unused frames travel as they are)
+    const size_t count = size_t(frames) * g->stride;                              // floats per rank
     if (g->transport == PT_GROUP_TRANSPORT_RCCL) {
-        // one collective per batch: every member sends its compact buffer over its own xGMI link to the root
+        // one collective per batch: every member sends its compact buffer over its own xGMI link to the root.  (Rank 0's de-interleave of
+        // the previous use of gathered[s] precedes this gather on its stream, and no peer's data lands before the root has posted it.)
         G_NCCL(g, g_rccl.GroupStart());
         for (uint32_t r = 0; r < g->n; ++r) {
             const ncclResult_t rc = g_rccl.Gather(g->compact[s][r], r == 0 ? g->gathered[s] : nullptr, count, kNcclFloat, 0, g->comm[r], g->stream[r]);
@@ -136,18 +147,23 @@ int gather_set(PtGroup* g, uint32_t s, uint32_t frames) {
         G_NCCL(g, g_rccl.GroupEnd());
     } else {
         // diagnostic transport: peer copies instead of the collective (members may share one GPU, which RCCL refuses) --
-        // same buffers, same order on every member's stream, so everything but the ncclGather call itself is exercised
+        // same buffers, same order on every member's stream, so everything but the ncclGather call itself is exercised.
+        // Nothing but an event orders a peer's copy into gathered[s] behind rank 0's de-interleave of what the set held two batches ago.
         for (uint32_t r = 0; r < g->n; ++r) {
             G_HIP(g, hipSetDevice(g->devices[r]));
+            if (g->consumed_valid[s]) G_HIP(g, hipStreamWaitEvent(g->stream[r], g->consumed[s], 0));
             G_HIP(g, hipMemcpyPeerAsync(g->gathered[s] + size_t(r) * count, g->devices[0], g->compact[s][r], g->devices[r], count * sizeof(float), g->stream[r]));
             G_HIP(g, hipEventRecord(g->ready[r], g->stream[r]));
         }
         G_HIP(g, hipSetDevice(g->devices[0]));
         for (uint32_t r = 1; r < g->n; ++r) G_HIP(g, hipStreamWaitEvent(g->stream[0], g->ready[r], 0));
     }
-    // rank r's share of frame j sits at gathered[s] + (r * batch + j) * stride
-    for (uint32_t j = 0; j < frames; ++j)
-        G_PT(g, 0, pt_deinterleave(g->ctx[0], g->gathered[s] + size_t(j) * g->stride, uint64_t(g->batch) * g->stride, g->width, g->height, g->n));
+    G_PT(g, 0, pt_deinterleave_batch(g->ctx[0], g->gathered[s], uint64_t(frames) * g->stride, g->stride, frames, g->width, g->height, g->n,
+                                     frames > 1u ? g->frames_out : nullptr, uint64_t(g->width) * g->height * 4ull));
+    if (g->transport != PT_GROUP_TRANSPORT_RCCL) {
+        G_HIP(g, hipSetDevice(g->devices[0]));
+        G_HIP(g, hipEventRecord(g->consumed[s], g->stream[0])); g->consumed_valid[s] = true;
+    }
     g->have_frame = true;
     return PT_OK;
 }
@@ -205,8 +221,18 @@ int pt_group_create(const int* device_ordinals, uint32_t num_devices, uint32_t t
         for (uint32_t r = 0; r < num_devices; ++r) {
             (void)hipSetDevice(g->devices[r]);
             if (hipEventCreateWithFlags(&g->ready[r], hipEventDisableTiming) != hipSuccess) { pt_group_destroy(g); return gfail(nullptr, PT_ERR_HIP, "pt_group_create: hipEventCreate"); }
-            if (g->devices[r] != g->devices[0]) { int can = 0; (void)hipDeviceCanAccessPeer(&can, g->devices[r], g->devices[0]); if (can) (void)hipDeviceEnablePeerAccess(g->devices[0], 0); }
+            if (g->devices[r] != g->devices[0]) {
+                int can = 0; (void)hipDeviceCanAccessPeer(&can, g->devices[r], g->devices[0]);
+                if (can) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(g->devices[0], 0);
+                    (void)hipGetLastError();      // "already enabled" (a second group over these GPUs) is success; never leave it behind for the next launch check
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { pt_group_destroy(g); return gfail(nullptr, PT_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe)); }
+                }
+            }
         }
+        (void)hipSetDevice(g->devices[0]);
+        for (int k = 0; k < 2; ++k)
+            if (hipEventCreateWithFlags(&g->consumed[k], hipEventDisableTiming) != hipSuccess) { pt_group_destroy(g); return gfail(nullptr, PT_ERR_HIP, "pt_group_create: hipEventCreate"); }
     }
     *out = g;
     return PT_OK;
@@ -218,6 +244,7 @@ void pt_group_destroy(PtGroup* g) {
     for (ncclComm_t c : g->comm) if (c) (void)g_rccl.CommDestroy(c);
     free_buffers(g);
     for (uint32_t r = 0; r < g->ready.size(); ++r) if (g->ready[r]) { (void)hipSetDevice(g->devices[r]); (void)hipEventDestroy(g->ready[r]); }
+    for (int k = 0; k < 2; ++k) if (g->consumed[k]) { (void)hipSetDevice(g->devices[0]); (void)hipEventDestroy(g->consumed[k]); }
     for (PtContext* c : g->ctx) if (c) pt_destroy(c);
     delete g;
 }

@@ -309,6 +309,17 @@ void tile_list(uint32_t width, uint32_t height, uint32_t rank, uint32_t count, s
             if ((tx + ty) % count == rank) tiles.push_back(ty * tx_n + tx);
 }
 
+uint32_t tile_count_of(uint32_t width, uint32_t height, uint32_t rank, uint32_t count) {
+    if (count == 0) count = 1;
+    const uint32_t tx_n = (width + kTile - 1) / kTile, ty_n = (height + kTile - 1) / kTile;
+    uint32_t n = 0;
+    for (uint32_t ty = 0; ty < ty_n; ++ty) {
+        const uint32_t first = (rank + count - ty % count) % count;
+        if (first < tx_n) n += (tx_n - first + count - 1) / count;
+    }
+    return n;
+}
+
 // ------------------------------------------------------------------------------------
 // Procedural stand-in scenes
 // ------------------------------------------------------------------------------------

@@ -66,5 +66,7 @@ bool procedural_scene(uint32_t kind, uint32_t seed, uint32_t num_tris, float* ou
 // ---- tiles ------------------------------------------------------------------------
 constexpr uint32_t kTile = 8;   // 8x8-pixel tiles, one wavefront each
 void tile_list(uint32_t width, uint32_t height, uint32_t rank, uint32_t count, std::vector<uint32_t>& tiles);
+// tile_list(...).size() without building the list: per tile row, the rank's tiles are tx = first, first + count, ... with first = (rank - ty) mod count
+uint32_t tile_count_of(uint32_t width, uint32_t height, uint32_t rank, uint32_t count);
 
 } // namespace pt

@@ -21,7 +21,7 @@
 #define PT_MEGA_BLOCK 64           // threads per workgroup of the persistent kernel: single-wave groups free their CU slot as soon as the wave drains
 #endif
 #ifndef PT_SHADE_THRESHOLD
-#define PT_SHADE_THRESHOLD 16       // lanes waiting for a shade pass before one runs (or nothing traverses); 16 measured best in long launches, 8..16 equal for single frames (tools/sweeps/tune26.sh)
+#define PT_SHADE_THRESHOLD 16       // lanes waiting for a shade pass before one runs (or nothing traverses); 16 measured best in long launches, 8..16 equal for single frames (tools/sweep.sh SHADE)
 #endif
 #ifndef PT_FLUSH_THRESHOLD
 #define PT_FLUSH_THRESHOLD 0       // >0: once the queue is dry, a wavefront with fewer live lanes donates its paths to the next pass (measured: no gain at <= 4 frame slots, so off)
@@ -112,7 +112,7 @@ struct RenderArgs {
 hipError_t launch_render(const RenderArgs& args, int kmode, bool stats, hipStream_t stream);
 // k0/k1 (optional): events recorded immediately around the trace_paths_kernel launches
 hipError_t launch_trace(const RenderArgs& args, bool stats, uint32_t grid_blocks, hipStream_t stream, hipEvent_t k0, hipEvent_t k1);
-hipError_t launch_prime(uint32_t* queue, float4* samples, uint32_t n_samples, hipStream_t stream);   // first use of a frame slot
+hipError_t launch_prime(uint32_t* queue, hipStream_t stream);   // first use of a frame slot: its control block zeroed
 // per-frame parameters and output targets of a launch into the slot's device arrays (asynchronous: the data travels as kernel arguments)
 hipError_t launch_frame_params(const FrameParams* frames, float4* const* outs, uint32_t n, FrameParams* d_frames, float4** d_outs, hipStream_t stream);
 hipError_t launch_resolve(const RenderArgs& args, hipStream_t stream);
@@ -141,8 +141,9 @@ hipError_t collapse_on_device(const BuildBuffers& B, const uint32_t* bvh2, uint3
 // B.subtree[i] = 1 for internal node id i, B.ids = its exclusive prefix sum (the wide-node index)
 hipError_t launch_internal_scan(const BuildBuffers& B, const uint32_t* bvh4, uint32_t num_nodes4, hipStream_t stream);
 hipError_t launch_wide_nodes(const BuildBuffers& B, const uint32_t* bvh4, uint32_t num_nodes4, uint4* wide, uint32_t num_tris, uint32_t node_base16, hipStream_t stream);
-hipError_t launch_deinterleave(const float4* gathered, uint64_t stride_px, float4* full, uint32_t width, uint32_t height,
-                               uint32_t count, hipStream_t stream);
+// gathered: rank r's share of frame j at gathered + r * rank_stride_px + j * frame_stride_px; frame j goes to full + j * full_stride_px
+hipError_t launch_deinterleave(const float4* gathered, uint64_t rank_stride_px, uint64_t frame_stride_px, uint32_t frames, float4* full, uint64_t full_stride_px,
+                               uint32_t width, uint32_t height, uint32_t count, hipStream_t stream);
 hipError_t launch_rgba8(const float4* src, uint32_t* dst, uint32_t n, hipStream_t stream);
 hipError_t launch_tonemap(const float4* src, uint32_t* dst, uint32_t width, uint32_t height, int from_rgba8, hipStream_t stream);
 

@@ -470,8 +470,9 @@ __global__ __launch_bounds__(256) void lbvh2_leaves_kernel(uint32_t* bvh2, const
 // ------------------------------------------------------------------------------------
 // post passes
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void deinterleave_kernel(const float4* __restrict__ gathered, uint64_t stride_px, float4* __restrict__ full,
-                                                           uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t tiles_y, uint32_t count) {
+// blockIdx.y = frame of the batch: every frame of a gathered batch is scattered by ONE launch
+__global__ __launch_bounds__(256) void deinterleave_kernel(const float4* __restrict__ gathered, uint64_t stride_px, uint64_t frame_stride_px, float4* __restrict__ full,
+                                                           uint64_t full_stride_px, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t tiles_y, uint32_t count) {
     const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tile = item >> 6, lane = item & 63u;
     if (tile >= tiles_x * tiles_y) return;
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const float4* __restr
     }
     const uint32_t first = (rank + count - (ty % count)) % count;
     slot += (tx - first) / count;
-    full[(size_t)py * width + px] = gathered[(size_t)rank * stride_px + (size_t)slot * 64 + lane];
+    full[(size_t)blockIdx.y * full_stride_px + (size_t)py * width + px] = gathered[(size_t)rank * stride_px + (size_t)blockIdx.y * frame_stride_px + (size_t)slot * 64 + lane];
 }
 
 __global__ __launch_bounds__(256) void rgba8_kernel(const float4* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
@@ -560,10 +561,12 @@ hipError_t launch_lbvh2_refit(uint32_t* bvh2, const uint32_t* parent, uint32_t* 
     return hipGetLastError();
 }
 
-hipError_t launch_deinterleave(const float4* gathered, uint64_t stride_px, float4* full, uint32_t width, uint32_t height, uint32_t count, hipStream_t stream) {
+hipError_t launch_deinterleave(const float4* gathered, uint64_t rank_stride_px, uint64_t frame_stride_px, uint32_t frames, float4* full, uint64_t full_stride_px,
+                               uint32_t width, uint32_t height, uint32_t count, hipStream_t stream) {
     const uint32_t tx = (width + 7) / 8, ty = (height + 7) / 8;
     const uint32_t items = tx * ty * 64u;
-    hipLaunchKernelGGL(deinterleave_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, gathered, stride_px, full, width, height, tx, ty, count);
+    if (frames == 0u) return hipSuccess;
+    hipLaunchKernelGGL(deinterleave_kernel, dim3((items + 255) / 256, frames), dim3(256), 0, stream, gathered, rank_stride_px, frame_stride_px, full, full_stride_px, width, height, tx, ty, count);
     return hipGetLastError();
 }
 

@@ -254,3 +254,91 @@ def test_prebuilt_bvh_files_roundtrip(rt, orc, gpu_ctx, tmp_path):
     with pytest.raises(rt.PtError):
         fresh.set_bvh2(bvh2[:-5])                              # truncated file
     fresh.close()
+
+
+def test_timing_ring_survives_a_launch_that_traces_nothing(rt, gpu_ctx):
+    """The root-box cull can remove every owned tile (scene in front of the eye but off-screen): the launch then has no items, and
+    the timing pair of the ring slot it consumed must still be recorded -- pt_timing_collect used to fail on never-recorded events
+    and leave the ring broken."""
+    tris = (random_soup(300, 2).reshape(-1, 3) * np.float32(0.05) + np.array([30.0, 0.0, -3.0], np.float32)).astype(np.float32).reshape(-1)   # far off to the right
+    gpu_ctx.set_triangles(tris); gpu_ctx.build_bvh()
+    p = gpu_ctx.make_params(96, 64, cam_pos=(0, 0, 2.5), mode=rt.PT_MODE_PATH, spp=2, max_bounces=2)
+    gpu_ctx.timing_begin(3)
+    gpu_ctx.render(p); gpu_ctx.render(p)
+    ms = gpu_ctx.timing_collect(3)
+    assert len(ms) == 2 and np.all(ms >= 0.0) and np.all(ms < 5.0)
+    img = gpu_ctx.read_radiance()
+    assert np.all(img[..., :3] == np.float32(0.01))
+    gpu_ctx.timing_begin(2)                      # and the ring is usable afterwards
+    gpu_ctx.render(p)
+    assert len(gpu_ctx.timing_collect(2)) == 1
+
+
+def test_buffer_busy_tracks_queued_and_delivered_frames(rt, gpu_ctx):
+    """pt_buffer_busy: a caller-owned target is busy while a frame queued by pt_set_batch (or still in flight) points into it, and
+    free once everything has been delivered; pt_set_output_buffer(NULL) launches what is queued AND waits for it."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    tris = random_soup(400, 5)
+    gpu_ctx.set_triangles(tris); gpu_ctx.build_bvh()
+    w, h = 64, 40
+    nbytes = w * h * 16
+    bufs = []
+    for _ in range(2):
+        ptr = C.c_void_p()
+        assert hip.hipMalloc(C.byref(ptr), C.c_size_t(nbytes)) == 0
+        bufs.append(ptr.value)
+    try:
+        gpu_ctx.set_batch(4)
+        p = gpu_ctx.make_params(w, h, mode=rt.PT_MODE_PATH, spp=2, max_bounces=2)
+        gpu_ctx.set_output_buffer(bufs[0], w * h * 4); gpu_ctx.render(p)
+        gpu_ctx.set_output_buffer(bufs[1], w * h * 4); p.frame = 1; gpu_ctx.render(p)
+        assert gpu_ctx.buffer_busy(bufs[0], nbytes) and gpu_ctx.buffer_busy(bufs[1], nbytes)      # queued, not launched yet
+        assert not gpu_ctx.buffer_busy(bufs[0] + nbytes, 16)
+        gpu_ctx.set_output_buffer(0, 0)                                                         # launches the partial batch and waits
+        assert not gpu_ctx.buffer_busy(bufs[0], nbytes) and not gpu_ctx.buffer_busy(bufs[1], nbytes)
+        out = np.zeros((h, w, 4), np.float32)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(bufs[1]), C.c_size_t(nbytes), C.c_int(2)) == 0
+        gpu_ctx.set_batch(1)
+        gpu_ctx.render(p)
+        assert same_bits(out, gpu_ctx.read_radiance())
+    finally:
+        for b in bufs:
+            hip.hipFree(C.c_void_p(b))
+
+
+def test_deinterleave_batch_scatters_every_frame_of_a_gathered_batch(rt, gpu_ctx):
+    """pt_deinterleave_batch: three frames, three tile shares rendered into one [rank][frame][stride] buffer (the layout a gather of
+    a batch leaves on the root), scattered by ONE launch into three row-major frames; each equals the whole-frame render."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    tris = random_soup(500, 7)
+    gpu_ctx.set_triangles(tris); gpu_ctx.build_bvh()
+    w, h, world, frames = 100, 52, 3, 3
+    stride = max(rt.tile_layout(w, h, r, world)[1] for r in range(world))
+    g_ptr, f_ptr = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(g_ptr), C.c_size_t(world * frames * stride * 4)) == 0
+    assert hip.hipMalloc(C.byref(f_ptr), C.c_size_t(frames * w * h * 16)) == 0
+    try:
+        for r in range(world):
+            for j in range(frames):
+                gpu_ctx.set_compact_buffer(g_ptr.value + (r * frames + j) * stride * 4, stride)
+                gpu_ctx.render(gpu_ctx.make_params(w, h, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=3, frame=j, tile_rank=r, tile_count=world))
+        gpu_ctx.synchronize()
+        gpu_ctx.deinterleave_batch(g_ptr.value, frames * stride, stride, frames, w, h, world, f_ptr.value, w * h * 4)
+        last = gpu_ctx.read_radiance(w, h).copy()                       # the read-backs see the last frame of the batch
+        got = np.zeros((frames, h, w, 4), np.float32)
+        gpu_ctx.synchronize()
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), f_ptr, C.c_size_t(got.nbytes), C.c_int(2)) == 0
+        gpu_ctx.set_compact_buffer(0, 0)
+        for j in range(frames):
+            gpu_ctx.render(gpu_ctx.make_params(w, h, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=3, frame=j))
+            assert same_bits(got[j], gpu_ctx.read_radiance()), j
+        assert same_bits(last, got[frames - 1])
+        # the context's own frame buffer as the target: only the last frame is scattered
+        gpu_ctx.deinterleave_batch(g_ptr.value, frames * stride, stride, frames, w, h, world)
+        assert same_bits(gpu_ctx.read_radiance(w, h), got[frames - 1])
+        with pytest.raises(rt.PtError):
+            gpu_ctx.deinterleave_batch(g_ptr.value, stride, stride, frames, w, h, world, f_ptr.value, w * h * 4)     # rank stride too small for three frames
+    finally:
+        hip.hipFree(g_ptr); hip.hipFree(f_ptr)

@@ -87,3 +87,25 @@ def test_group_errors(rt):
     with pytest.raises(rt.PtError):
         g.set_batch(0)
     g.close()
+
+
+def test_group_many_batches_in_flight_without_host_waits(rt, scene):
+    """Five batches of three frames submitted back to back (no read-back in between): each buffer set is re-used while earlier
+    batches may still be gathering / de-interleaving -- the copy transport orders the peers' next copy into a set behind rank 0's
+    de-interleave of what the set held before (pt_group.cpp: `consumed`).  The result is the last frame; frames of distinct
+    indices differ, so a frame assembled from two batches would show."""
+    g = rt.Group([0, 0, 0], rt.PT_GROUP_TRANSPORT_COPY)
+    try:
+        g.set_triangles(scene); g.build_bvh()
+        one = rt.Context(0); one.set_triangles(scene); one.build_bvh()
+        g.set_batch(3)
+        w, h = 320, 200
+        for f in range(15):
+            g.render(g.make_params(w, h, mode=rt.PT_MODE_PATH, spp=2, max_bounces=4, seed=6, frame=f))
+        got = g.read_radiance()
+        one.render(one.make_params(w, h, mode=rt.PT_MODE_PATH, spp=2, max_bounces=4, seed=6, frame=14))
+        assert same_bits(got, one.read_radiance())
+        one.close()
+    finally:
+        g.close()
+

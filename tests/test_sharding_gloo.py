@@ -60,6 +60,9 @@ def _worker(rank, world, port, width, height, result_path):
     stride = max(rt.tile_layout(width, height, r, world)[1] for r in range(world))
     nt, fl = rt.tile_layout(width, height, rank, world)
     assert nt == len(owned_tiles(width, height, rank, world)) and fl == nt * 256
+    # the order of the compact buffer is the PRODUCT's (pt_tile_ids = the list pt_render uploads): this test's own enumeration must equal it
+    tx_n = (width + 7) // 8
+    assert [ty * tx_n + tx for tx, ty in owned_tiles(width, height, rank, world)] == rt.tile_ids(width, height, rank, world).tolist()
     mine = torch.from_numpy(compact_from_full(full, rank, world, stride))
     glist = [torch.empty(stride) for _ in range(world)] if rank == 0 else None
     work = dist.gather(mine, glist, dst=0, async_op=True)
@@ -87,10 +90,11 @@ def _bench_module():
     return mod
 
 
-@pytest.mark.parametrize("n_steps,batch,world", [(20, 20, 1), (256, 32, 1), (20, 20, 8), (256, 256, 8), (256, 64, 2), (7, 32, 4), (1, 1, 8)])
+@pytest.mark.parametrize("n_steps,batch,world", [(20, 20, 1), (256, 32, 1), (20, 20, 8), (256, 256, 8), (256, 64, 2), (7, 32, 4), (1, 1, 8), (5, 5, 8), (3, 160, 8)])
 def test_bench_launch_schedule_covers_every_step_once(n_steps, batch, world):
-    """bench.py's launches: every step in exactly one launch, in order, no launch larger than a batch; a sharded run's launches
-    shrink towards the end (its last gather is exposed), a single-GPU run uses full batches."""
+    """bench.py's launches: every step in exactly one launch, in order, no launch larger than a batch; a sharded run is cut into
+    at least SHARD_PIECES launches of about equal size (its last gather and drain are exposed, the earlier gathers travel behind the
+    next launch), never growing towards the end; a single-GPU run uses full batches."""
     bench = _bench_module()
     launches = bench.schedule(n_steps, batch, world, False)
     assert launches[0][0] == 0
@@ -99,13 +103,39 @@ def test_bench_launch_schedule_covers_every_step_once(n_steps, batch, world):
         assert first == done and 1 <= nf <= batch
         done += nf
     assert done == n_steps
+    sizes = [nf for _, nf in launches]
     if world == 1:
-        assert all(nf == batch for _, nf in launches[:-1])
+        assert all(nf == batch for nf in sizes[:-1])
     else:
-        sizes = [nf for _, nf in launches]
-        assert all(a >= b for a, b in zip(sizes, sizes[1:])) or sizes[-1] <= 8
-        assert sizes[-1] <= max(8, n_steps // 2)
+        assert len(sizes) == min(n_steps, max(bench.SHARD_PIECES, -(-n_steps // batch)))
+        assert all(a >= b for a, b in zip(sizes, sizes[1:])) and max(sizes) - min(sizes) <= 1
     assert bench.schedule(n_steps, batch, world, True) == [(i, min(batch, n_steps - i)) for i in range(0, n_steps, batch)]
+
+
+def test_bench_schedule_for_the_drivers_own_sharded_command():
+    """`--gpus 8 --steps 20 --warmup 5`: four launches of five share-frames (was 10 / 8 / 2), the warm-up 2 / 1 / 1 / 1."""
+    bench = _bench_module()
+    cap = min(32 * 8, 256, 20)
+    assert [nf for _, nf in bench.schedule(20, cap, 8, False)] == [5, 5, 5, 5]
+    assert [nf for _, nf in bench.schedule(5, cap, 8, False)] == [2, 1, 1, 1]
+    assert [nf for _, nf in bench.schedule(256, 256, 8, False)] == [64, 64, 64, 64]
+
+
+def test_bench_submit_launches_is_the_sequence_both_callers_replay():
+    """bench.py and tools/shard_schedule_sim.py submit through one function: per launch its frames with the target set first, a flush
+    for a partial batch, then the caller's hook."""
+    bench = _bench_module()
+    calls = []
+
+    class Ctx:
+        def render(self, p): calls.append(("render", p.frame))
+        def flush(self): calls.append(("flush",))
+
+    class P: frame = 0
+
+    bench.submit_launches(Ctx(), P(), [(0, 2), (2, 1)], 100, 2, lambda k, j, f: calls.append(("target", k, j, f)), lambda k, nf: calls.append(("after", k, nf)))
+    assert calls == [("target", 0, 0, 100), ("render", 100), ("target", 0, 1, 101), ("render", 101), ("after", 0, 2),
+                     ("target", 1, 0, 102), ("render", 102), ("flush",), ("after", 1, 1)]
 
 
 def test_bench_busy_time_is_the_union_of_launch_intervals():
@@ -113,3 +143,19 @@ def test_bench_busy_time_is_the_union_of_launch_intervals():
     assert bench.busy_ms([0.0, 10.0], [5.0, 5.0]) == pytest.approx(10.0)          # disjoint
     assert bench.busy_ms([0.0, 2.0], [5.0, 5.0]) == pytest.approx(7.0)            # overlapping: never the sum of the spans
     assert bench.busy_ms([0.0, 1.0, 20.0], [10.0, 2.0, 1.0]) == pytest.approx(11.0)   # contained + disjoint
+
+
+@pytest.mark.parametrize("width,height,world", [(64, 40, 2), (70, 33, 2), (1920, 1080, 8), (17, 9, 3), (8, 8, 5), (333, 77, 7)])
+def test_tile_ids_are_the_interleaved_order_for_every_rank(width, height, world):
+    """pt_tile_ids (product code, the list pt_render uploads) against the specification: row-major over the tiles with
+    (tx + ty) % world == rank; pt_tile_layout's closed-form count agrees; the ranks partition the tile grid."""
+    rt = importlib.import_module("raytracer-public_amd")
+    tx_n, ty_n = (width + 7) // 8, (height + 7) // 8
+    seen = []
+    for rank in range(world):
+        ids = rt.tile_ids(width, height, rank, world).tolist()
+        assert ids == [ty * tx_n + tx for tx, ty in owned_tiles(width, height, rank, world)]
+        nt, fl = rt.tile_layout(width, height, rank, world)
+        assert nt == len(ids) and fl == nt * 256
+        seen += ids
+    assert sorted(seen) == list(range(tx_n * ty_n))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The counter side of bench.py's roofline: rocprofv3 --pmc passes (one counter group per run, never combined with tracing) and one
 # --kernel-trace --stats run over THE COMMAND THE DRIVER RUNS (`python3 bench.py --steps 20 --warmup 5`), reduced to per-frame totals of
-# the timed trace_paths_kernel launches -> profiles/r02_pmc_bench.json (+ kernel stats CSV).  bench.py writes the order of its launches
+# the timed trace_paths_kernel launches -> profiles/r03_pmc_bench.json (+ kernel stats CSV).  bench.py writes the order of its launches
 # (warm-up / timed / reference call shape) to a side file, so the timed dispatches are picked by position, not guessed.
 # usage (on the GPU box): tools/pmc_bench.sh <outdir-under-gpurun_out> [bench.py arguments, default: --steps 20 --warmup 5]
 set -u
@@ -19,4 +19,5 @@ for CNT in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SAL
   cp $OUT/launch_log.json $OUT/launch_log_pass$i.json 2>/dev/null
 done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS --no-cpu-baseline > $OUT/trace.log 2>&1 || echo "kernel-trace run failed" >> $OUT/errors.txt
+cp $OUT/launch_log.json $OUT/launch_log_trace.json 2>/dev/null
 python3 $ROOT/tools/pmc_bench_reduce.py $OUT "python3 bench.py $ARGS"

@@ -50,7 +50,35 @@ for f in glob.glob(os.path.join(out_dir, "trace/**/*kernel_stats.csv"), recursiv
         if "trace_paths_kernel" in row["Name"] or "resolve_kernel" in row["Name"]:
             stats[row["Name"]] = {k: row[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs") if k in row}
     os.system("cp %s %s" % (f, os.path.join(out_dir, "kernel_stats.csv")))
-res = {"command": command, "source_tag": source_tag(), "kernel": KERNEL, "steps": steps,
+# kernel busy time per frame in THIS session (the box the counters were taken on): union of the timed trace_paths_kernel dispatches
+# of the --kernel-trace run, picked by position from that run's own launch log
+builder_busy = None
+try:
+    log = json.load(open(os.path.join(out_dir, "launch_log_trace.json")))
+    spans = []
+    for f in glob.glob(os.path.join(out_dir, "trace/**/*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if KERNEL in row.get("Kernel_Name", "").replace("false,false", "false, false"):
+                spans.append((int(row["Dispatch_Id"]), int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+    spans.sort()
+    if len(spans) == len(log["launches"]):
+        iv = sorted((a, b) for k, (_, a, b) in enumerate(spans) if log["launches"][k][0] == "timed")
+        total, cur_a, cur_b = 0, None, None
+        for a, b in iv:
+            if cur_b is None or a > cur_b:
+                if cur_b is not None:
+                    total += cur_b - cur_a
+                cur_a, cur_b = a, b
+            else:
+                cur_b = max(cur_b, b)
+        if cur_b is not None:
+            total += cur_b - cur_a
+        builder_busy = total / 1e6 / log["steps"]
+    else:
+        print("kernel trace: %d dispatches of %s, launch log has %d -- no builder-side busy time" % (len(spans), KERNEL, len(log["launches"])))
+except Exception as e:
+    print("no builder-side busy time:", e)
+res = {"command": command, "builder_kernel_busy_ms_per_frame": builder_busy, "source_tag": source_tag(), "kernel": KERNEL, "steps": steps,
        "frames_per_launch": steps / max(launches_seen.get("SQ_INSTS_VALU", 1), 1), "timed_launches": launches_seen.get("SQ_INSTS_VALU"),
        "per_frame": per_frame, "kernel_stats": stats,
        "how": "tools/pmc_bench.sh: one rocprofv3 --pmc pass per counter group over the command above; the timed launches are identified by "
