@@ -294,7 +294,7 @@ def test_buffer_busy_tracks_queued_and_delivered_frames(rt, gpu_ctx):
         gpu_ctx.set_output_buffer(bufs[0], w * h * 4); gpu_ctx.render(p)
         gpu_ctx.set_output_buffer(bufs[1], w * h * 4); p.frame = 1; gpu_ctx.render(p)
         assert gpu_ctx.buffer_busy(bufs[0], nbytes) and gpu_ctx.buffer_busy(bufs[1], nbytes)      # queued, not launched yet
-        assert not gpu_ctx.buffer_busy(bufs[0] + nbytes, 16)
+        assert not gpu_ctx.buffer_busy(bufs[0] + 16, nbytes - 16)                                # a range no frame starts in
         gpu_ctx.set_output_buffer(0, 0)                                                         # launches the partial batch and waits
         assert not gpu_ctx.buffer_busy(bufs[0], nbytes) and not gpu_ctx.buffer_busy(bufs[1], nbytes)
         out = np.zeros((h, w, 4), np.float32)
