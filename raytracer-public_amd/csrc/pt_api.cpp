@@ -41,16 +41,16 @@ struct DevBuf {
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto,
-             flush = kAuto, passes = kAuto, slots = kAuto, cull = kAuto, stats_batch = kAuto;
+             consolidate = kAuto, slots = kAuto, cull = kAuto, stats_batch = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"FLUSH", &PtTune::flush}, {"PASSES", &PtTune::passes}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}};
+            {"FILL", &PtTune::fill}, {"CONSOLIDATE", &PtTune::consolidate}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "FLUSH", "PASSES", "SLOTS", "CULL", "STATSBATCH"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "CONSOLIDATE", "SLOTS", "CULL", "STATSBATCH"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -96,7 +96,9 @@ struct PtContext {
     // dense start of the next; the resolve passes stay in call order on the main stream.
     struct FrameSlot {
         hipStream_t side = nullptr; hipEvent_t resolved = nullptr, done = nullptr; bool used = false;
-        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<uint4> rays; DevBuf<float4> cont; DevBuf<uint32_t> flags;
+        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<uint4> rays;
+        // drain consolidation: per-SIMD state words / published heads / hardware-key table (one allocation), record rings, flags; launches of the slot so far
+        DevBuf<unsigned long long> simd_ctl; DevBuf<float4> simd_pool; DevBuf<uint32_t> simd_flags; uint32_t simd_launches = 0;
         // owned-tile slots that the launch in this slot traces (the others are culled: every camera ray misses the root box)
         DevBuf<uint32_t> trace_slots; uint32_t* h_trace = nullptr; size_t h_trace_cap = 0; hipEvent_t trace_copied = nullptr;
         uint32_t cull_key[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t num_trace_tiles = 0; bool cull_valid = false;
@@ -326,8 +328,9 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         A.xcd_span = PtTune::pick(ctx->tune.xcd, work8_q >= 64u ? 1u : 0u) ? ((per + A.chunk_items - 1u) / A.chunk_items) * A.chunk_items : 0u;
     }
     A.shade_threshold = PtTune::pick(ctx->tune.shade, PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD);
-    A.flush_threshold = PtTune::pick(ctx->tune.flush, sharded ? 0u : PT_FLUSH_THRESHOLD);   // sharded frames are too small to profit from a second pass
-    A.cont_passes = PtTune::pick(ctx->tune.passes, PT_MAX_CONT_PASSES);
+    // drain consolidation: only paths that bounce have ray boundaries to be handed over at
+    A.consolidate = (A.ref_mode == 0u && A.max_bounces != 0u) ? PtTune::pick(ctx->tune.consolidate, PT_CONSOLIDATE) : 0u;
+    A.simd_slots = ptk::kSimdSlots; A.simd_cap = ptk::kSimdCap;
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
     // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
     // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small
@@ -348,7 +351,6 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     const size_t cap_samples = std::max(n_samples, size_t(A.batches_per_frame) * 64u * size_t(ctx->batch_size));
     if (cap_samples > 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: batch too large (more than 2^32 samples per launch)");
     const uint32_t full_lanes = ptk::megakernel_grid(cus) * ptk::megakernel_block();
-    A.pool_capacity = full_lanes * 2u;           // donations can repeat; a full pool just stops donating
     for (int si = 0; si < (stats ? 1 : setup_slots); ++si) {
         PtContext::FrameSlot& s = ctx->slots[si];
         if (!s.side) {
@@ -360,8 +362,15 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         PT_HIP(ctx, s.samples.ensure(cap_samples));
         PT_HIP(ctx, s.spill.ensure(size_t(full_lanes) * size_t(64 - PT_SHORT_STACK)));
         PT_HIP(ctx, s.rays.ensure(size_t(full_lanes) * 3u));          // 64 ray records of 3 x uint4 per wavefront
-        PT_HIP(ctx, s.cont.ensure(A.cont_passes ? size_t(A.pool_capacity) * 4u * 2u : 4u));
-        PT_HIP(ctx, s.flags.ensure(A.cont_passes ? size_t(A.pool_capacity) * 2u : 4u));
+        if (A.consolidate) {
+            // [state words | published heads | hardware-key table + id counter] in one allocation (8-byte units), rings of 64 B records, one flag each
+            const size_t ctl_words64 = size_t(ptk::kSimdSlots) + (size_t(ptk::kSimdSlots) + ptk::kSimdKeys + 1u + 1u) / 2u + 1u;
+            const bool fresh = s.simd_flags.ptr == nullptr;
+            PT_HIP(ctx, s.simd_ctl.ensure(ctl_words64));
+            PT_HIP(ctx, s.simd_pool.ensure(size_t(ptk::kSimdSlots) * ptk::kSimdCap * 4u));
+            PT_HIP(ctx, s.simd_flags.ensure(size_t(ptk::kSimdSlots) * ptk::kSimdCap));
+            if (fresh) { PT_HIP(ctx, hipMemsetAsync(s.simd_flags.ptr, 0, size_t(ptk::kSimdSlots) * ptk::kSimdCap * sizeof(uint32_t), s.side)); s.simd_launches = 0; }
+        }
         PT_HIP(ctx, s.frame_params.ensure(std::max<size_t>(ctx->batch_size, nf))); PT_HIP(ctx, s.frame_outs.ensure(std::max<size_t>(ctx->batch_size, nf)));
         if (s.primed_ptr != (const void*)s.samples.ptr || s.primed_samples < cap_samples) {
             if (s.used) PT_HIP(ctx, hipStreamWaitEvent(s.side, s.resolved, 0));
@@ -371,7 +380,21 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     }
     PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(want_slots))];
     A.prime = stats ? 1u : 0u;                   // instrumented launches start from a freshly primed prefix
-    A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.raybuf = sl.rays.ptr; A.pool = sl.cont.ptr; A.pool_flags = sl.flags.ptr;
+    A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.raybuf = sl.rays.ptr;
+    if (A.consolidate) {
+        A.simd_state = sl.simd_ctl.ptr;
+        A.simd_head = (uint32_t*)(sl.simd_ctl.ptr + ptk::kSimdSlots);
+        A.simd_ids = A.simd_head + ptk::kSimdSlots;
+        A.simd_pool = sl.simd_pool.ptr; A.simd_flags = sl.simd_flags.ptr;
+        // a flag is (epoch + absolute record index + 1): the epoch moves on by 2^20 per launch of the slot, so no stale flag of an earlier
+        // launch can pass for this one's; every 4,000 launches the flags are cleared and the count starts again
+        if (sl.simd_launches >= 4000u) {
+            if (sl.used) PT_HIP(ctx, hipStreamWaitEvent(sl.side, sl.resolved, 0));
+            PT_HIP(ctx, hipMemsetAsync(sl.simd_flags.ptr, 0, size_t(ptk::kSimdSlots) * ptk::kSimdCap * sizeof(uint32_t), sl.side));
+            sl.simd_launches = 0;
+        }
+        A.simd_epoch = (++sl.simd_launches) << 20;
+    }
     A.trace_slots = nullptr;
     if (cull) {
         // the list travels through a pinned staging buffer of the slot; it is rebuilt only when the rectangle (or the tile share) changes
@@ -414,7 +437,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     if (stats) {
         // the counter blocks are zeroed on the stream the instrumented kernel runs on, behind everything that stream still has
         // to wait for; the previous reader (pt_get_stats / pt_debug_*) copied them synchronously
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(unsigned long long), sl.side));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 24 * sizeof(unsigned long long), sl.side));
         PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(stat_waves) * 16u * 8u, sl.side));
     }
     {   // per-frame parameters and targets into the slot's device arrays; a frame whose target a later frame of this launch
@@ -480,7 +503,7 @@ int pt_create(int device_ordinal, PtContext** out) {
     }
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop);
-    if (e == hipSuccess) e = ctx->d_stats.ensure(16);
+    if (e == hipSuccess) e = ctx->d_stats.ensure(24);
     if (e == hipSuccess) { hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, dev); if (e == hipSuccess) ctx->num_cus = prop.multiProcessorCount; }
     if (e != hipSuccess) { int rc = fail_hip(nullptr, e, "pt_create"); pt_destroy(ctx); return rc; }
     ctx->stream = ctx->own_stream;
@@ -503,8 +526,9 @@ void pt_destroy(PtContext* ctx) {
     if (ctx->h_word) (void)hipHostFree(ctx->h_word);
     for (auto& sl : ctx->slots) {
         sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.rays.release(); sl.trace_slots.release();
+        sl.simd_ctl.release(); sl.simd_pool.release(); sl.simd_flags.release();
         if (sl.h_trace) (void)hipHostFree(sl.h_trace);
-        if (sl.trace_copied) (void)hipEventDestroy(sl.trace_copied); sl.cont.release(); sl.flags.release(); sl.frame_params.release(); sl.frame_outs.release();
+        if (sl.trace_copied) (void)hipEventDestroy(sl.trace_copied); sl.frame_params.release(); sl.frame_outs.release();
         if (sl.resolved) (void)hipEventDestroy(sl.resolved);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.side) { (void)hipStreamSynchronize(sl.side); (void)hipStreamDestroy(sl.side); }
@@ -905,7 +929,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         if (!mega_path) {      // the megakernel zeroes the block itself, on the stream its trace runs on (flush_pending_stats)
             if (int rc = flush_pending(ctx)) return rc;
             ctx->stats_culled = 0;
-            PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(unsigned long long), ctx->stream));
+            PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 24 * sizeof(unsigned long long), ctx->stream));
         }
         A.stats = ctx->d_stats.ptr;
     }
@@ -1030,9 +1054,9 @@ int pt_debug_set_tune(PtContext* ctx, const char* name, uint32_t value) {
 }
 
 /* diagnostics (not in the public header): raw counter block of the last STATS launch */
-int pt_debug_counters(PtContext* ctx, unsigned long long* dst16) {
+int pt_debug_counters(PtContext* ctx, unsigned long long* dst24) {
     if (int rc = bind(ctx)) return rc;
-    PT_HIP(ctx, hipMemcpy(dst16, ctx->d_stats.ptr, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    PT_HIP(ctx, hipMemcpy(dst24, ctx->d_stats.ptr, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

@@ -23,11 +23,8 @@
 #ifndef PT_SHADE_THRESHOLD
 #define PT_SHADE_THRESHOLD 16       // lanes waiting for a shade pass before one runs (or nothing traverses); 16 measured best in long launches, 8..16 equal for single frames (tools/sweep.sh SHADE)
 #endif
-#ifndef PT_FLUSH_THRESHOLD
-#define PT_FLUSH_THRESHOLD 0       // >0: once the queue is dry, a wavefront with fewer live lanes donates its paths to the next pass (measured: no gain at <= 4 frame slots, so off)
-#endif
-#ifndef PT_MAX_CONT_PASSES
-#define PT_MAX_CONT_PASSES 1       // continuation passes after pass 0 (the last one runs every path to its end)
+#ifndef PT_CONSOLIDATE
+#define PT_CONSOLIDATE 1           // drain consolidation: once the queue is dry the wavefronts of a SIMD hand their paths to one collector (pt_megakernel.hip)
 #endif
 #ifndef PT_FILL_THRESHOLD
 #define PT_FILL_THRESHOLD 4        // hand out ready camera rays when this many lanes of a wavefront are without a path (a fetch from the ray buffer is cheap: 4 beats 8 by 2 %)
@@ -35,6 +32,9 @@
 
 namespace ptk {
 
+constexpr uint32_t kSimdKeys = 8192;     // hardware keys: xcc (3 bits) | se, sh, cu (8 bits) | simd (2 bits)
+constexpr uint32_t kSimdSlots = 1280;    // dense SIMD ids a launch can deal (MI355X: 1,024 SIMDs); a wavefront beyond that keeps its paths
+constexpr uint32_t kSimdCap = 512;       // records per SIMD ring (a power of two); 6 x 64 of them stay free for simultaneous reservations
 #define PT_MAX_BATCH 256    // frames per persistent launch (their per-frame parameters live in a small device array)
 // Per-frame part of the UBO for a batched launch (several consecutive frames traced by one persistent launch).
 struct FrameParams {
@@ -96,11 +96,13 @@ struct RenderArgs {
     uint32_t  xcd_span;                   // 0: one queue; else items per XCD range (8 cursors at queue[8..15])
     uint32_t  num_batches, perm_cols;     // real (frame, traced tile, sample) batches of the queue; columns of the batch transpose
     uint32_t  perm_rows, perm_rows_magic; // its rows and floor(2^32 / rows) for the division
-    // path pool: 64 B records (o, d, T, rad, key, item, bounce) donated by sparse wavefronts once the queue is dry;
-    // they are the input of the continuation pass (off by default: PT_FLUSH_THRESHOLD 0)
-    float4*   pool; uint32_t* pool_flags; uint32_t* pool_ctrl;      // ctrl: [0] reserved tail, [1] claimed head
-    const float4* in_pool; const uint32_t* in_ctrl;                  // previous pass's pool (continuation passes)
-    uint32_t  pool_capacity, flush_threshold, cont_passes;
+    // drain consolidation (pt_megakernel.hip): per SIMD one 64-bit state word (bits 0..7 registered wavefronts, bit 8 collector present,
+    // bits 32..63 records reserved), the collector's published read position, a ring of simd_cap 64 B path records (o, d, T, rad, key, item,
+    // bounce) with one flag each (= simd_epoch + absolute index + 1 once the record is complete); simd_ids: hardware key -> dense SIMD id + 1
+    // (dealt on first use; [kSimdKeys] is the id counter)
+    unsigned long long* simd_state; uint32_t* simd_head; uint32_t* simd_ids;
+    float4*   simd_pool; uint32_t* simd_flags;
+    uint32_t  simd_slots, simd_cap, simd_epoch, consolidate;
     uint32_t  shade_threshold, fill_threshold;
     // batched launch: frames[i] / outs[i] for i < num_frames; items of frame i are batches [i*batches_per_frame, ...)
     const FrameParams* frames; float4* const* outs;     // device arrays of the frame slot, filled by launch_frame_params

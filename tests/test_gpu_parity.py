@@ -254,25 +254,44 @@ def test_sponza_class_interior_bit_exact(rt, orc, gpu_ctx):
     assert (ids != 0xFFFFFFFF).mean() > 0.9        # interior: nearly every camera ray hits
 
 
-def test_donation_and_continuation_passes_bit_exact(rt, gpu_ctx):
-    """The optional drain scheme (sparse wavefronts park at a ray boundary, donate their paths as 64 B records,
-    continuation passes pick them up) changes scheduling only: the image and the counters stay the same."""
+def test_drain_consolidation_bit_exact(rt, gpu_ctx):
+    """Drain consolidation (once the queue is dry the wavefronts of a SIMD hand their paths, at ray boundaries, to one collector) changes
+    scheduling only: image and counters are the same with it and without it, in single launches, batches and tile shares -- and paths
+    do move (the instrumented launch counts hand-overs), none is lost, every SIMD that registers has exactly one collector at a time."""
+    import ctypes as C
     tris = rt.procedural_scene(0, 60000)
     gpu_ctx.set_triangles(tris)
     gpu_ctx.build_bvh()
     kw = dict(mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, seed=2)
+    gpu_ctx.debug_set_tune("CONSOLIDATE", 0)
     gpu_ctx.render(gpu_ctx.make_params(640, 360, stats=True, **kw))
     want = gpu_ctx.read_radiance().copy(); st0 = gpu_ctx.stats()
-    for flush, passes in ((24, 1), (48, 2), (63, 3)):
-        gpu_ctx.debug_set_tune("FLUSH", flush); gpu_ctx.debug_set_tune("PASSES", passes)
+    dbg = np.zeros(24, np.uint64); rt.lib.pt_debug_counters(gpu_ctx.h, dbg.ctypes.data_as(C.c_void_p))
+    assert dbg[16] == 0 and dbg[17] == 0 and dbg[20] == 0 and dbg[21] == 0            # off: nothing registers, nothing moves
+    gpu_ctx.debug_set_tune("CONSOLIDATE", 1)
+    for rep in range(3):
         gpu_ctx.render(gpu_ctx.make_params(640, 360, stats=True, **kw))
         got = gpu_ctx.read_radiance().copy(); st = gpu_ctx.stats()
-        assert same_bits(got, want), (flush, passes)
-        for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples"):
-            assert st[k] == st0[k], (k, flush, passes)
-        gpu_ctx.render(gpu_ctx.make_params(640, 360, **kw))
+        assert same_bits(got, want), rep
+        for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples", "max_stack", "stack_drops"):
+            assert st[k] == st0[k], (k, rep)
+        rt.lib.pt_debug_counters(gpu_ctx.h, dbg.ctypes.data_as(C.c_void_p))
+        donated, adopted, lost, donors, collectors = (int(dbg[k]) for k in (16, 17, 18, 20, 21))
+        assert donated > 0 and adopted == donated and lost == 0, (donated, adopted, lost)
+        assert collectors > 0 and donors > 0
+        gpu_ctx.render(gpu_ctx.make_params(640, 360, **kw))                               # the production kernel
         assert same_bits(gpu_ctx.read_radiance(), want)
-    gpu_ctx.debug_set_tune("FLUSH"); gpu_ctx.debug_set_tune("PASSES")
+    # batches and a tile share with consolidation on, against the same frames without it
+    gpu_ctx.set_batch(3)
+    outs = {}
+    for cons in (0, 1):
+        gpu_ctx.debug_set_tune("CONSOLIDATE", cons)
+        for f in range(3):
+            gpu_ctx.render(gpu_ctx.make_params(320, 200, frame=f, **kw))
+        outs[cons] = gpu_ctx.read_radiance().copy()
+    assert same_bits(outs[0], outs[1])
+    gpu_ctx.set_batch(1)
+    gpu_ctx.debug_set_tune("CONSOLIDATE")
 
 
 def test_batched_launch_equals_frame_by_frame(rt, gpu_ctx):

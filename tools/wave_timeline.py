@@ -46,6 +46,7 @@ for k in order:
 post = w[live, 3] - w[live, 6]
 print("iterations after queue-empty: p50 %d p90 %d p99 %d max %d; longest path ended after (steps): p50 %d p90 %d p99 %d max %d" %
       (tuple(np.percentile(post, [50, 90, 99, 100])) + tuple(np.percentile(w[live, 14], [50, 90, 99, 100]))))
-dbg = np.zeros(16, np.uint64); rt.lib.pt_debug_counters(ctx.h, dbg.ctypes.data_as(C.c_void_p))
+dbg = np.zeros(24, np.uint64); rt.lib.pt_debug_counters(ctx.h, dbg.ctypes.data_as(C.c_void_p))
 print('pushes %d, at depth>=8 %.2f%%, >=12 %.2f%%, spilled(>=kShort) %.3f%%' % (dbg[8], 100.0 * dbg[9] / dbg[8], 100.0 * dbg[10] / dbg[8], 100.0 * dbg[11] / dbg[8]))
+print('drain consolidation: %d paths handed over, %d fetched, %d lost; wavefronts: %d never registered, %d donors, %d collectors, %d without a slot' % tuple(int(dbg[k]) for k in (16, 17, 18, 19, 20, 21, 22)))
 print('longest path %d traversal steps, longest ray %d; paths >= 512 steps: %d, >= 1024: %d' % (dbg[12], dbg[13], dbg[14], dbg[15]))
