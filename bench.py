@@ -48,6 +48,9 @@ BYTES_NODE, BYTES_TRI, BYTES_SAMPLE = 32, 36, 16
 SIMDS, VALU_CYCLES_PER_WAVE_INST, CLOCK_HZ = 1024, 2.0, 2.4e9
 VALU_PEAK_GINST = SIMDS * CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST / 1e9
 L2_PEAK_GBS, L2_LINE, HBM_PEAK_GBS = 34500.0, 128, 8000.0
+# the vector L1's request rate for this access pattern (every lane gathers its own 64-byte record with 4 x dwordx4): 217.7 G records/s x 4
+# requests, measured chip-wide by tools/probes/gather64.hip (profiles/r03_gather64_probe.txt, V0) -- 1.42 requests per cycle and CU
+L1_GATHER_PEAK_GREQ = 217.7 * 4
 PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
 KERNEL_SOURCES = ["pt_megakernel.hip", "pt_device.h", "pt_kernels.h"]
 VERIFY_STEP = 16
@@ -459,7 +462,8 @@ def main():
             s = busy_per_frame * 1e-3
 
             def fracs(sec):
-                return {"valu_issue": c["SQ_INSTS_VALU"] / sec / 1e9 / VALU_PEAK_GINST,
+                extra = {"l1_gather_requests": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / sec / 1e9 / L1_GATHER_PEAK_GREQ} if "TCP_TOTAL_CACHE_ACCESSES_sum" in c else {}
+                return {**extra, "valu_issue": c["SQ_INSTS_VALU"] / sec / 1e9 / VALU_PEAK_GINST,
                         "l2_bandwidth": (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE / sec / 1e9 / L2_PEAK_GBS,
                         "hbm_fabric": (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / sec / 1e9 / HBM_PEAK_GBS}
 
@@ -473,7 +477,8 @@ def main():
             lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
             traffic = int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 * frames_per_launch)
             bound = max(fractions, key=fractions.get)
-            roof = {"valu_issue": ("valu", c["SQ_INSTS_VALU"] / s / 1e9, VALU_PEAK_GINST, "Ginst/s"),
+            roof = {"l1_gather_requests": ("l1", c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / s / 1e9, L1_GATHER_PEAK_GREQ, "Greq/s"),
+                    "valu_issue": ("valu", c["SQ_INSTS_VALU"] / s / 1e9, VALU_PEAK_GINST, "Ginst/s"),
                     "l2_bandwidth": ("l2", (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE / s / 1e9, L2_PEAK_GBS, "GB/s"),
                     "hbm_fabric": ("hbm", (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / s / 1e9, HBM_PEAK_GBS, "GB/s")}[bound]
         else:
@@ -490,7 +495,8 @@ def main():
             "pmc": pmc_info,
             "definition": "frac = (per-frame counter total of the timed launches, rocprofv3 --pmc of this command, profiles/) / (kernel busy time per frame, hipEvents of this run) / peak; "
                           "valu_issue: SQ_INSTS_VALU x 2 cycles over 1024 SIMDs x 2.4 GHz; l2_bandwidth: (TCC_HIT+TCC_MISS) x 128 B over 34.5 TB/s; "
-                          "hbm_fabric: (FETCH_SIZE+WRITE_SIZE) x 1024 over 8 TB/s (FETCH_SIZE includes Infinity-Cache hits); bound = the largest; fractions_over_builder_time = the same "
+                          "hbm_fabric: (FETCH_SIZE+WRITE_SIZE) x 1024 over 8 TB/s (FETCH_SIZE includes Infinity-Cache hits); l1_gather_requests: TCP_TOTAL_CACHE_ACCESSES over the "
+                          "request rate a pure 64-byte-record gather sustains (871 G/s, tools/probes/gather64.hip); bound = the largest; fractions_over_builder_time = the same "
                           "counters over the kernel time of the session the counters were taken in (another box: the two sets differ by the boxes' speed difference)",
             "algorithmic": {"GBps": round(algorithmic_gbs, 2), "bytes_per_frame": int(my_bytes), "bytes_per_frame_min_max": [int(min(frame_bytes)), int(max(frame_bytes))],
                             "over_hbm_peak": round(algorithmic_gbs / HBM_PEAK_GBS, 4),
