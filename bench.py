@@ -486,7 +486,7 @@ def main():
         roofline = {
             "bound": roof[0], "achieved": None if roof[1] is None else round(roof[1], 2), "peak": roof[2], "unit": roof[3],
             "frac": None if roof[1] is None else round(roof[1] / roof[2], 5), "traffic": traffic,
-            "kernel": "trace_paths_kernel<false,false> (persistent megakernel)",
+            "kernel": "trace_paths_kernel<false> (persistent megakernel)",
             "kernel_busy_ms": round(busy, 4), "kernel_busy_ms_per_frame": round(busy_per_frame, 5), "launches": int(len(k_ms)),
             "kernel_avg_launch_ms": round(float(np.mean(k_ms)), 4) if len(k_ms) else None, "frames_per_launch": frames_per_launch,
             "fractions": {k: round(v, 5) for k, v in fractions.items()},

@@ -4,7 +4,7 @@ import collections, csv, glob, hashlib, json, os, sys
 
 out_dir, command = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "trace_paths_kernel<false, false>"
+KERNEL = "trace_paths_kernel<false>"
 
 
 def _normalised_source(path):
@@ -34,7 +34,7 @@ for p in sorted(glob.glob(os.path.join(out_dir, "pass*/"))):
     rows = collections.OrderedDict()          # counter -> {dispatch id: value}; dispatch ids grow in submission order
     for f in glob.glob(p + "**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if KERNEL not in row.get("Kernel_Name", "").replace("false,false", "false, false"):
+            if KERNEL not in row.get("Kernel_Name", ""):
                 continue
             rows.setdefault(row["Counter_Name"], {})[int(row["Dispatch_Id"])] = float(row["Counter_Value"])
     for name, by_id in rows.items():
@@ -58,7 +58,7 @@ try:
     spans = []
     for f in glob.glob(os.path.join(out_dir, "trace/**/*kernel_trace.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if KERNEL in row.get("Kernel_Name", "").replace("false,false", "false, false"):
+            if KERNEL in row.get("Kernel_Name", ""):
                 spans.append((int(row["Dispatch_Id"]), int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
     spans.sort()
     if len(spans) == len(log["launches"]):
