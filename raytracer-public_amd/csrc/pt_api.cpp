@@ -41,16 +41,16 @@ struct DevBuf {
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto,
-             consolidate = kAuto, split = kAuto, slots = kAuto, cull = kAuto, stats_batch = kAuto;
+             consolidate = kAuto, slots = kAuto, cull = kAuto, stats_batch = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"CONSOLIDATE", &PtTune::consolidate}, {"SPLIT", &PtTune::split}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}};
+            {"FILL", &PtTune::fill}, {"CONSOLIDATE", &PtTune::consolidate}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "CONSOLIDATE", "SPLIT", "SLOTS", "CULL", "STATSBATCH"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "CONSOLIDATE", "SLOTS", "CULL", "STATSBATCH"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -331,7 +331,6 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     // drain consolidation: only paths that bounce have ray boundaries to be handed over at
     A.consolidate = (A.ref_mode == 0u && A.max_bounces != 0u) ? PtTune::pick(ctx->tune.consolidate, PT_CONSOLIDATE) : 0u;
     A.simd_slots = ptk::kSimdSlots; A.simd_cap = ptk::kSimdCap;
-    A.split = (A.ref_mode == 0u && A.max_bounces != 0u) ? PtTune::pick(ctx->tune.split, PT_SPLIT) : 0u;
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
     // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
     // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small

@@ -23,9 +23,6 @@
 #ifndef PT_SHADE_THRESHOLD
 #define PT_SHADE_THRESHOLD 16       // lanes waiting for a shade pass before one runs (or nothing traverses); 16 measured best in long launches, 8..16 equal for single frames (tools/sweep.sh SHADE)
 #endif
-#ifndef PT_SPLIT
-#define PT_SPLIT 0                 // ray splitting: idle lanes of a sparse wavefront traverse stacked subtrees of a traversing lane's ray (pt_megakernel.hip)
-#endif
 #ifndef PT_CONSOLIDATE
 #define PT_CONSOLIDATE 1           // drain consolidation: once the queue is dry the wavefronts of a SIMD hand their paths to one collector (pt_megakernel.hip)
 #endif
@@ -106,7 +103,6 @@ struct RenderArgs {
     unsigned long long* simd_state; uint32_t* simd_head; uint32_t* simd_ids;
     float4*   simd_pool; uint32_t* simd_flags;
     uint32_t  simd_slots, simd_cap, simd_epoch, consolidate;
-    uint32_t  split;            // ray splitting in sparse wavefronts once the queue is dry (pt_megakernel.hip)
     uint32_t  shade_threshold, fill_threshold;
     // batched launch: frames[i] / outs[i] for i < num_frames; items of frame i are batches [i*batches_per_frame, ...)
     const FrameParams* frames; float4* const* outs;     // device arrays of the frame slot, filled by launch_frame_params

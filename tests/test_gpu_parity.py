@@ -294,48 +294,6 @@ def test_drain_consolidation_bit_exact(rt, gpu_ctx):
     gpu_ctx.debug_set_tune("CONSOLIDATE")
 
 
-@pytest.mark.parametrize("cons", [0, 1])
-def test_ray_splitting_bit_exact(rt, orc, gpu_ctx, cons):
-    """Ray splitting (idle lanes of a sparse wavefront traverse stacked subtrees of a traversing lane's ray once the queue is dry) changes
-    scheduling only.  Checked against the run without it and against the oracle: an open scene, an interior (every ray hits, long paths),
-    lone frames and batches, whole frames and a tile share -- and a scene in which EVERY triangle exists twice, so that every closest hit
-    is an exact tie in t between two triangles and the answer is the reference's traversal order (renderer.wgsl:202): the split traversal
-    must notice each such ray and trace it again alone."""
-    kw = dict(mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, seed=3)
-    gpu_ctx.debug_set_tune("CONSOLIDATE", cons)
-    scenes = [("dragon-class", rt.procedural_scene(0, 60000), (0, 0, 2.5), (0, 0, 0, 1)),
-              ("sponza-class", rt.procedural_scene(1, 30000), (0.55, -0.05, 0.05), (0.0, 0.6630, 0.0, 0.7486))]
-    soup = rt.procedural_scene(0, 4000).reshape(-1, 9)
-    scenes.append(("every triangle twice", np.concatenate([soup, soup]).reshape(-1).copy(), (0, 0, 2.5), (0, 0, 0, 1)))
-    for name, tris, cam, quat in scenes:
-        gpu_ctx.set_triangles(tris); gpu_ctx.build_bvh()
-        bvh4 = gpu_ctx.read_bvh4()
-        w, h = (320, 200) if name != "dragon-class" else (640, 360)
-        want, _, _ = orc.render(orc.make_params(w, h, tris.size // 9, cam, quat, mode=orc_mod.MODE_PATH, spp=4, max_bounces=8, seed=3), tris, bvh4)
-        for split in (0, 1, 1):
-            gpu_ctx.debug_set_tune("SPLIT", split)
-            gpu_ctx.render(gpu_ctx.make_params(w, h, cam, quat, **kw))
-            assert same_bits(gpu_ctx.read_radiance(), want), (name, split)
-        # a batch of three frames and a 1/3 tile share, split on, against split off
-        res = {}
-        for split in (0, 1):
-            gpu_ctx.debug_set_tune("SPLIT", split)
-            gpu_ctx.set_batch(3)
-            for f in range(3):
-                gpu_ctx.render(gpu_ctx.make_params(w, h, cam, quat, frame=f, **kw))
-            full = gpu_ctx.read_radiance().copy()
-            gpu_ctx.set_batch(1)
-            gpu_ctx.render(gpu_ctx.make_params(w, h, cam, quat, frame=1, tile_rank=1, tile_count=3, **kw))
-            ptr, fl = gpu_ctx.compact_radiance()
-            import ctypes as C
-            share = np.zeros(fl, np.float32)
-            gpu_ctx.synchronize()
-            assert C.CDLL("libamdhip64.so").hipMemcpy(share.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(fl * 4), C.c_int(2)) == 0
-            res[split] = (full, share)
-        assert same_bits(res[0][0], res[1][0]) and same_bits(res[0][1], res[1][1]), name
-    gpu_ctx.debug_set_tune("SPLIT"); gpu_ctx.debug_set_tune("CONSOLIDATE")
-
-
 def test_batched_launch_equals_frame_by_frame(rt, gpu_ctx):
     """pt_set_batch: several frames traced by one persistent launch give exactly the per-frame results
     (each into the output target that was current at submission), including an accumulating sequence."""
