@@ -109,3 +109,36 @@ def test_group_many_batches_in_flight_without_host_waits(rt, scene):
     finally:
         g.close()
 
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: the RCCL gather with more than one rank (the one-GPU boxes of this pool skip it)")
+def test_group_rccl_two_members_on_two_gpus(rt, scene):
+    """ncclCommInitAll over two devices + one ncclGather per batch with two ranks: whole frames, a batch with a partial tail, an accumulating
+    sequence -- bit for bit against one context.  The only test in which the collective itself moves another rank's data."""
+    g = rt.Group([0, 1], rt.PT_GROUP_TRANSPORT_RCCL)
+    try:
+        g.set_triangles(scene); g.build_bvh()
+        one = rt.Context(0); one.set_triangles(scene); one.build_bvh()
+        kw = dict(mode=rt.PT_MODE_PATH, spp=2, max_bounces=4, seed=8)
+        for (w, h) in ((256, 144), (97, 61)):
+            g.render(g.make_params(w, h, frame=3, **kw)); one.render(one.make_params(w, h, frame=3, **kw))
+            assert same_bits(g.read_radiance(), one.read_radiance()), (w, h)
+        g.set_batch(4)
+        for f in range(7):
+            g.render(g.make_params(256, 144, frame=f, **kw))
+        one.render(one.make_params(256, 144, frame=6, **kw))
+        assert same_bits(g.read_radiance(), one.read_radiance())
+        for f in range(3):
+            g.render(g.make_params(256, 144, frame=20 + f, accumulate=True, **kw)); one.render(one.make_params(256, 144, frame=20 + f, accumulate=True, **kw))
+        assert same_bits(g.read_radiance(), one.read_radiance())
+        one.close()
+    finally:
+        g.close()
