@@ -861,6 +861,38 @@ void orc_cosine_dir(const float n[3], float u1, float u2, float out[3]) { V3 r =
 // tonemapper.wgsl:24-41: Reinhard + gamma 1/2.2 with the vertical flip of the full-screen
 // triangle (uv.y = 0 at the bottom of the canvas; row 0 of the canvas is its top).
 // in: W*H*4 f32 (the renderer's rgba8unorm-quantised output if quantize != 0), out: W*H*4 u8
+// x^(1/2.2) for x in [0, 1], BUILD-DEFINED pinned f32 evaluation (WGSL leaves pow's precision implementation-defined, tonemapper.wgsl:36):
+// x = m 2^e, m in [sqrt(1/2), sqrt(2)); ln m = 2 atanh((m-1)/(m+1)) as an odd polynomial (fmaf); z = log2(x) / 2.2; 2^z = 2^floor(z) times a
+// degree-7 polynomial in the fraction (fmaf).  The HIP tonemap kernel evaluates the same sequence.
+static float pow_1_2_2(float x) {
+    if (!(x > 1.17549435e-38f)) return 0.0f;
+    if (x >= 1.0f) return 1.0f;
+    uint32_t bits; std::memcpy(&bits, &x, 4);
+    int e = int(bits >> 23) - 127;
+    uint32_t mb = (bits & 0x007fffffu) | 0x3f800000u; float m; std::memcpy(&m, &mb, 4);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const float s = (m - 1.0f) / (m + 1.0f), s2 = s * s;
+    float p = std::fmaf(s2, 0.11111111f, 0.14285715f);
+    p = std::fmaf(s2, p, 0.2f);
+    p = std::fmaf(s2, p, 0.33333334f);
+    p = std::fmaf(s2, p, 1.0f);
+    const float ln_m = 2.0f * s * p;
+    const float z = (float(e) + ln_m * 1.44269504f) * 0.45454547f;
+    const float kf = std::floor(z), r = z - kf;
+    float q = std::fmaf(r, 1.5252734e-5f, 1.5403530e-4f);
+    q = std::fmaf(r, q, 1.3333558e-3f);
+    q = std::fmaf(r, q, 9.6181291e-3f);
+    q = std::fmaf(r, q, 5.5504109e-2f);
+    q = std::fmaf(r, q, 2.4022651e-1f);
+    q = std::fmaf(r, q, 6.9314718e-1f);
+    q = std::fmaf(r, q, 1.0f);
+    const int k = int(kf);
+    if (k < -126) return 0.0f;
+    uint32_t sb = uint32_t(k + 127) << 23; float sc; std::memcpy(&sc, &sb, 4);
+    return q * sc;
+}
+float orc_pow_1_2_2(float x) { return pow_1_2_2(x); }
+
 void orc_tonemap(const float* rgba, uint32_t W, uint32_t H, int quantize, uint8_t* out) {
     for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) {
         uint32_t sy = H - 1 - y;
@@ -870,7 +902,7 @@ void orc_tonemap(const float* rgba, uint32_t W, uint32_t H, int quantize, uint8_
             float c = p[k];
             if (quantize) { float q = c < 0.f ? 0.f : (c > 1.f ? 1.f : c); c = std::floor(q * 255.0f + 0.5f) / 255.0f; }
             float m = c / (c + 1.0f);
-            float g = std::pow(m, 1.0f / 2.2f);
+            float g = pow_1_2_2(m);
             float q = g < 0.f ? 0.f : (g > 1.f ? 1.f : g);
             o[k] = uint8_t(std::floor(q * 255.0f + 0.5f));
         }

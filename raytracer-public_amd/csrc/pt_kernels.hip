@@ -501,6 +501,37 @@ __global__ __launch_bounds__(256) void rgba8_kernel(const float4* __restrict__ s
     dst[i] = q(c.x) | (q(c.y) << 8) | (q(c.z) << 16) | (q(c.w) << 24);
 }
 
+// x^(1/2.2) for x in [0, 1] as ONE pinned f32 evaluation (WGSL leaves pow's precision to the implementation, and libm's powf differs from the
+// device's by an LSB of the 8-bit result): x = m 2^e with m in [sqrt(1/2), sqrt(2)); ln m = 2 atanh(s), s = (m - 1) / (m + 1), as an odd
+// polynomial in s evaluated with fmaf; z = (e + ln m / ln 2) / 2.2; 2^z = 2^k 2^r with k = floor(z), r in [0, 1): a degree-7 polynomial with
+// fmaf, the scale by exponent arithmetic.  Only +, -, *, /, fmaf, floorf and integer operations: bit-identical to oracle/pt_oracle.cpp::pow_1_2_2.
+__device__ __forceinline__ float pow_1_2_2(float x) {
+    if (!(x > 1.17549435e-38f)) return 0.0f;                       // zero, negatives, subnormals, NaN
+    if (x >= 1.0f) return 1.0f;                                     // the Reinhard curve stays below 1
+    uint32_t bits = __float_as_uint(x);
+    int e = (int)(bits >> 23) - 127;
+    float m = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u);  // [1, 2)
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }                  // [sqrt(1/2), sqrt(2))
+    const float s = (m - 1.0f) / (m + 1.0f), s2 = s * s;
+    float p = __builtin_fmaf(s2, 0.11111111f, 0.14285715f);
+    p = __builtin_fmaf(s2, p, 0.2f);
+    p = __builtin_fmaf(s2, p, 0.33333334f);
+    p = __builtin_fmaf(s2, p, 1.0f);
+    const float ln_m = 2.0f * s * p;
+    const float z = ((float)e + ln_m * 1.44269504f) * 0.45454547f;  // log2(x) / 2.2
+    const float kf = floorf(z), r = z - kf;
+    float q = __builtin_fmaf(r, 1.5252734e-5f, 1.5403530e-4f);      // 2^r = sum (r ln 2)^n / n!
+    q = __builtin_fmaf(r, q, 1.3333558e-3f);
+    q = __builtin_fmaf(r, q, 9.6181291e-3f);
+    q = __builtin_fmaf(r, q, 5.5504109e-2f);
+    q = __builtin_fmaf(r, q, 2.4022651e-1f);
+    q = __builtin_fmaf(r, q, 6.9314718e-1f);
+    q = __builtin_fmaf(r, q, 1.0f);
+    const int k = (int)kf;
+    if (k < -126) return 0.0f;
+    return q * __uint_as_float((uint32_t)(k + 127) << 23);
+}
+
 // tonemapper.wgsl:24-41 (Reinhard, gamma 1/2.2) with the vertical flip of the full-screen pass
 __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__ src, uint32_t* __restrict__ dst, uint32_t width, uint32_t height, int from_rgba8) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -510,7 +541,7 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__
     auto tm = [from_rgba8](float v) {
         if (from_rgba8) { v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); v = floorf(v * 255.0f + 0.5f) / 255.0f; }
         const float m = v / (v + 1.0f);
-        float g = powf(m, 1.0f / 2.2f);
+        float g = pow_1_2_2(m);
         g = g < 0.0f ? 0.0f : (g > 1.0f ? 1.0f : g);
         return (uint32_t)floorf(g * 255.0f + 0.5f);
     };

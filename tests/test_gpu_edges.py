@@ -106,7 +106,9 @@ def test_rgba8_and_tonemap_match_oracle(rt, orc, gpu_ctx):
     assert np.array_equal(gpu_ctx.read_rgba8(), want8)
     tm = gpu_ctx.read_tonemapped(True).astype(np.int32)
     ref = orc.tonemap(img, quantize=True).astype(np.int32)                          # tonemapper.wgsl + vertical flip
-    assert np.abs(tm - ref).max() <= 1                                              # powf: 1 LSB tolerance, f32 pow is not pinned
+    assert np.array_equal(tm, ref)                                                  # x^(1/2.2) is one pinned f32 evaluation on both sides (pow_1_2_2): bit for bit
+    tm2 = gpu_ctx.read_tonemapped(False).astype(np.int32)
+    assert np.array_equal(tm2, orc.tonemap(img, quantize=False).astype(np.int32))
 
 
 @pytest.fixture(scope="module")

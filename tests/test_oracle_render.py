@@ -160,3 +160,19 @@ def test_path_mode_shadowing_and_bounce_energy(orc):
     assert floor_lit.sum() > 500 and floor_dark.sum() > 20                  # both regions exist
     assert (multi[..., :3] >= direct[..., :3] - 1e-6).all()                 # bounces only add light
     assert multi[floor_dark][:, 0].mean() > 0.05                            # sky light reaches the shadow
+
+
+def test_pinned_gamma_curve_is_accurate_enough_for_eight_bits(orc):
+    """pow_1_2_2 (the one f32 evaluation of x^(1/2.2) both the oracle and the HIP tonemap kernel use, so that the tonemapped bytes are
+    bit-identical) against float64 pow: relative error below 5e-6 everywhere, the 8-bit result equal except next to a rounding boundary."""
+    import ctypes as C
+    orc.lib.orc_pow_1_2_2.restype = C.c_float; orc.lib.orc_pow_1_2_2.argtypes = [C.c_float]
+    xs = np.concatenate([np.linspace(0, 1, 20001, dtype=np.float32), (np.float32(10.0) ** np.linspace(-30, 0, 500)).astype(np.float32)])
+    got = np.array([orc.lib.orc_pow_1_2_2(float(x)) for x in xs], np.float64)
+    ref = np.minimum(np.where(xs > 1.2e-38, np.power(xs.astype(np.float64), 1 / 2.2), 0.0), 1.0)
+    big = xs > 1e-30
+    assert (np.abs(got - ref)[big] / ref[big]).max() < 5e-6
+    q = lambda g: np.floor(np.clip(g, 0, 1) * 255 + 0.5)
+    differ = q(got) != q(ref)
+    assert differ.sum() <= 5 and np.all(np.abs(ref[differ] * 255 + 0.5 - np.round(ref[differ] * 255 + 0.5)) < 1e-3)
+    assert orc.lib.orc_pow_1_2_2(0.0) == 0.0 and orc.lib.orc_pow_1_2_2(1.0) == 1.0 and orc.lib.orc_pow_1_2_2(-1.0) == 0.0
