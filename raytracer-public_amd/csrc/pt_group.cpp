@@ -141,10 +141,12 @@ int gather_set(PtGroup* g, uint32_t s, uint32_t frames) {
         // the previous use of gathered[s] precedes this gather on its stream, and no peer's data lands before the root has posted it.)
         G_NCCL(g, g_rccl.GroupStart());
         for (uint32_t r = 0; r < g->n; ++r) {
+            (void)hipSetDevice(g->devices[r]);                 // the documented single-process pattern: the rank's device is current when its call is issued
             const ncclResult_t rc = g_rccl.Gather(g->compact[s][r], r == 0 ? g->gathered[s] : nullptr, count, kNcclFloat, 0, g->comm[r], g->stream[r]);
             if (rc != 0) { (void)g_rccl.GroupEnd(); return gfail(g, PT_ERR_HIP, std::string("ncclGather: ") + g_rccl.GetErrorString(rc)); }
         }
         G_NCCL(g, g_rccl.GroupEnd());
+        G_HIP(g, hipSetDevice(g->devices[0]));
     } else {
         // diagnostic transport: peer copies instead of the collective (members may share one GPU, which RCCL refuses) --
         // same buffers, same order on every member's stream, so everything but the ncclGather call itself is exercised.
