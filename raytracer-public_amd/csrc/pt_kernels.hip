@@ -2,7 +2,7 @@
 //   * render_rays_kernel      the per-pixel-sample hot path of renderer.wgsl (ray generation,
 //                             BVH4 traversal, Moller-Trumbore, shade) + the build-defined
 //                             path-tracing extension, one ray per lane
-//   * render_packet_kernel    the literal 2x2-packet form of renderer.wgsl:355-413
+//   * render_packet_kernel    the literal 2x2-packet form of renderer.wgsl:355-413, four lanes of a quad = the four rays of a packet
 //   * lbvh2_internal_kernel / lbvh2_leaves_kernel   BVHBuilder.wgsl:152-306
 //   * deinterleave_kernel, tonemap/quantise kernels
 //
@@ -248,8 +248,19 @@ __global__ __launch_bounds__(256) void render_rays_kernel(const RenderArgs A) {
 }
 
 // ------------------------------------------------------------------------------------
-// Literal 2x2-packet kernel (renderer.wgsl:355-413): one thread per packet, reference-layout
-// BVH4 and 9-float triangles, shared 64-entry stack with a 4-bit lane mask per entry.
+// The reference's own traversal, literally: traverseBVH4Packet (renderer.wgsl:210-346) with its 2x2 ray packets, the shared
+// 64-entry stack with a 4-lane mask per entry, the double node fetch, the nearest-child swap and the silent drop -- laid out for
+// the wavefront machine instead of one thread per packet: the FOUR LANES OF A QUAD are the four rays of a packet (16 packets per
+// wavefront).  What the WGSL keeps per thread in private arrays becomes
+//   * the packet's stack: 64 entries of (node, lane mask) in LDS, one column per packet, bank-conflict free for any mix of depths
+//     (entry i of packet q at (i * 64 + q) * 8; the quad's four lanes read the same address);
+//   * a lane mask: the quad's nibble of a wavefront ballot;
+//   * "min over the packet's hit lanes": two v_min_f32 with DPP quad permutes;
+//   * a node fetch: one 32 B record read by the four lanes at the same address (one L1 request for the quad), the four child
+//     records of an internal node requested together.
+// Everything that steers the traversal (popped entry, masks, child distances, order, pushes) is identical in the four lanes of a
+// quad by construction, so a quad never diverges; packets of a wavefront do, like rays in the one-ray kernels.
+// Reference layouts throughout (BVH u32[1 + 8 M], triangles f32[9 N]): this is the fidelity mode, PT_MODE_REFERENCE_PACKET.
 // ------------------------------------------------------------------------------------
 struct PNode { F3 mn, mx; uint32_t c[4]; uint32_t tri; bool leaf; };
 __device__ __forceinline__ PNode load_ref_node(const uint32_t* __restrict__ bvh, uint32_t i) {   // renderer.wgsl:91-111
@@ -262,105 +273,127 @@ __device__ __forceinline__ PNode load_ref_node(const uint32_t* __restrict__ bvh,
     n.leaf = (p[7] & kLeaf) != 0u; n.tri = p[7] & 0x7fffffffu;
     return n;
 }
-__device__ __forceinline__ uint32_t packet_aabb(const Ray* rays, F3 mn, F3 mx, uint32_t in_mask, const float* best, float& min_t) {
-    min_t = kInfT;                                          // renderer.wgsl:121-169
-    if (mn.x > mx.x || mn.y > mx.y || mn.z > mx.z) return 0u;
-    uint32_t out = 0u; float m = kInfT;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (!(in_mask & (1u << i))) continue;
-        const F3 t1 = (mn - rays[i].o) * rays[i].inv, t2 = (mx - rays[i].o) * rays[i].inv;
-        const float tmin = wmax(wmax(wmin(t1.x, t2.x), wmin(t1.y, t2.y)), wmin(t1.z, t2.z));
-        const float tmax = wmin(wmin(wmax(t1.x, t2.x), wmax(t1.y, t2.y)), wmax(t1.z, t2.z));
-        if ((tmax >= wmax(tmin, 0.0f)) && (tmin < best[i])) { out |= 1u << i; m = wmin(m, tmin); }
-    }
-    min_t = out ? m : kInfT;
-    return out;
+__device__ __forceinline__ bool degenerate_box(const PNode& n) { return n.mn.x > n.mx.x || n.mn.y > n.mx.y || n.mn.z > n.mx.z; }
+// this lane's part of intersectAABBPacketMask (renderer.wgsl:147-159): hit flag and tmin of its own ray
+__device__ __forceinline__ bool lane_aabb(const Ray& r, F3 mn, F3 mx, float best, float& tmin_out) {
+    const F3 t1 = (mn - r.o) * r.inv, t2 = (mx - r.o) * r.inv;
+    const float tmin = wmax(wmax(wmin(t1.x, t2.x), wmin(t1.y, t2.y)), wmin(t1.z, t2.z));
+    const float tmax = wmin(wmin(wmax(t1.x, t2.x), wmax(t1.y, t2.y)), wmax(t1.z, t2.z));
+    tmin_out = tmin;
+    return (tmax >= wmax(tmin, 0.0f)) && (tmin < best);
+}
+// the quad's nibble of a wavefront mask (bit k = lane k of this lane's quad)
+__device__ __forceinline__ uint32_t quad_nibble(unsigned long long m, uint32_t lane) { return (uint32_t)(m >> (lane & 60u)) & 15u; }
+// minimum over the four lanes of a quad (every lane gets it): quad_perm [1,0,3,2] then [2,3,0,1]
+__device__ __forceinline__ float quad_min(float v) {
+    float o = __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xf, 0xf, true));
+    v = wmin(v, o);
+    o = __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x4E, 0xf, 0xf, true));
+    return wmin(v, o);
 }
 
 __global__ __launch_bounds__(256) void render_packet_kernel(const RenderArgs A) {
-    const uint32_t gx = blockIdx.x * 16u + (threadIdx.x & 15u), gy = blockIdx.y * 16u + (threadIdx.x >> 4);
-    const uint32_t bx = gx * 2u, by = gy * 2u;
-    if (bx >= A.width || by >= A.height) return;
-    Ray rays[4]; uint32_t lanes = 0u;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t px = bx + (i & 1), py = by + (i >> 1);
-        if (px < A.width && py < A.height) { lanes |= 1u << i; rays[i] = primary_ray(A, (float)px + 0.5f, (float)py + 0.5f); }
-        else { rays[i].o = f3(0, 0, 0); rays[i].d = f3(0, 0, -1.0f); rays[i].inv = f3(kInfT, kInfT, kInfT); }
-    }
-    float best[4] = {kInfT, kInfT, kInfT, kInfT};
-    uint32_t btri[4] = {kInvalidRef, kInvalidRef, kInvalidRef, kInvalidRef};
-    F3 bn[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bn[i] = f3(0, 0, 0);
+    __shared__ uint2 pstack[kStackMax][64];                  // [entry][packet of the block]: (node index, lane mask)
+    const uint32_t lane = threadIdx.x & 63u, sub = threadIdx.x & 3u;
+    const uint32_t pk = threadIdx.x >> 2;                    // packet of the block: 8 x 8 packets = 16 x 16 pixels
+    const uint32_t gx = blockIdx.x * 8u + (pk & 7u), gy = blockIdx.y * 8u + (pk >> 3);
+    const uint32_t px = gx * 2u + (sub & 1u), py = gy * 2u + (sub >> 1);
+    const bool in_image = px < A.width && py < A.height;     // renderer.wgsl:376-385: lanes outside the image stay inactive
+    Ray r;
+    if (in_image) r = primary_ray(A, (float)px + 0.5f, (float)py + 0.5f);
+    else { r.o = f3(0, 0, 0); r.d = f3(0, 0, -1.0f); r.inv = f3(kInfT, kInfT, kInfT); }
+    float best = kInfT; uint32_t btri = kInvalidRef; F3 bn = f3(0, 0, 0);
+    const uint32_t lanes0 = quad_nibble(__ballot(in_image), lane);          // the packet's initial lane mask
     const uint32_t num_nodes = A.bvh4_ref[0];
-    if (num_nodes != 0u && A.num_tris != 0u && lanes != 0u) {
-        uint32_t stack[kStackMax]; uint8_t smask[kStackMax]; int sp = 0;
-        stack[0] = 0u; smask[0] = (uint8_t)lanes;
-        while (sp >= 0) {
-            const uint32_t ni = stack[sp]; const uint32_t lm = smask[sp]; --sp;
-            const PNode node = load_ref_node(A.bvh4_ref, ni);
-            if (node.mn.x > node.mx.x || node.mn.y > node.mx.y || node.mn.z > node.mx.z) continue;
-            float nmin; const uint32_t hm = packet_aabb(rays, node.mn, node.mx, lm, best, nmin);
-            if (!hm) continue;
-            if (node.leaf) {
-                if (node.tri < A.num_tris) {
-                    const float* tp = A.tris9 + (size_t)node.tri * 9;
-                    const F3 v0 = f3(tp[0], tp[1], tp[2]), v1 = f3(tp[3], tp[4], tp[5]), v2 = f3(tp[6], tp[7], tp[8]);
-                    const F3 e1 = v1 - v0, e2 = v2 - v0;
-                    const F3 tn = normalize3(cross3(e1, e2));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (!(hm & (1u << i))) continue;
-                        const F3 p = cross3(rays[i].d, e2);
-                        const float det = dot3(e1, p);
-                        if (fabsf(det) < kTriEps) continue;
+    int sp = -1;
+    if (num_nodes != 0u && A.num_tris != 0u && lanes0 != 0u) { sp = 0; if (sub == 0u) pstack[0][pk] = make_uint2(0u, lanes0); }     // renderer.wgsl:224-233
+    // (one wavefront holds whole quads, so a packet's LDS accesses are ordered by its own wavefront: no barrier is needed)
+    while (__ballot(sp >= 0) != 0ull) {
+        const bool live = sp >= 0;
+        uint32_t ni = 0u, lm = 0u;
+        if (live) { const uint2 e = pstack[sp][pk]; ni = e.x; lm = e.y; --sp; }
+        PNode node;
+        if (live) node = load_ref_node(A.bvh4_ref, ni);
+        bool go = live && !degenerate_box(node);             // renderer.wgsl:244-246
+        float tmin = kInfT;
+        const bool hit = go && ((lm >> sub) & 1u) != 0u && lane_aabb(r, node.mn, node.mx, best, tmin);
+        const uint32_t hm = quad_nibble(__ballot(hit), lane);    // re-test at pop with the current best t (renderer.wgsl:248-252)
+        go = go && hm != 0u;
+        if (go && node.leaf) {
+            if (node.tri < A.num_tris) {                     // renderer.wgsl:262-283
+                const float* tp = A.tris9 + (size_t)node.tri * 9;
+                const F3 v0 = f3(tp[0], tp[1], tp[2]), v1 = f3(tp[3], tp[4], tp[5]), v2 = f3(tp[6], tp[7], tp[8]);
+                const F3 e1 = v1 - v0, e2 = v2 - v0;
+                const F3 tn = normalize3(cross3(e1, e2));
+                if ((hm >> sub) & 1u) {                      // intersectTrianglePacket, this lane (renderer.wgsl:185-205)
+                    const F3 p = cross3(r.d, e2);
+                    const float det = dot3(e1, p);
+                    if (!(fabsf(det) < kTriEps)) {
                         const float inv_det = 1.0f / det;
-                        const F3 s = rays[i].o - v0;
+                        const F3 s = r.o - v0;
                         const float u = inv_det * dot3(s, p);
-                        if (u < 0.0f || u > 1.0f) continue;
-                        const F3 q = cross3(s, e1);
-                        const float v = inv_det * dot3(rays[i].d, q);
-                        if (v < 0.0f || (u + v) > 1.0f) continue;
-                        const float t = inv_det * dot3(e2, q);
-                        if (t > kTriEps && t < best[i]) { best[i] = t; bn[i] = tn; btri[i] = node.tri; }
+                        if (!(u < 0.0f || u > 1.0f)) {
+                            const F3 q = cross3(s, e1);
+                            const float v = inv_det * dot3(r.d, q);
+                            if (!(v < 0.0f || (u + v) > 1.0f)) {
+                                const float t = inv_det * dot3(e2, q);
+                                if (t > kTriEps && t < best) { best = t; bn = tn; btri = node.tri; }
+                            }
+                        }
                     }
                 }
-                continue;
             }
-            uint32_t cidx[4]; float cdist[4]; uint32_t cmask[4]; int cc = 0;
+            go = false;
+        }
+        // internal node (renderer.wgsl:286-343): the four child records are requested together, tested by every lane of the mask
+        uint32_t cidx[4]; float cdist[4]; uint32_t cmask[4]; int cc = 0;
+        {
+            PNode ch[4]; bool valid[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t ci = node.c[c];
-                if (ci == kInvalidRef || ci >= num_nodes) continue;
-                const PNode ch = load_ref_node(A.bvh4_ref, ci);
-                if (ch.mn.x > ch.mx.x || ch.mn.y > ch.mx.y || ch.mn.z > ch.mx.z) continue;
-                float cm; const uint32_t m = packet_aabb(rays, ch.mn, ch.mx, hm, best, cm);
-                if (m) { cidx[cc] = ci; cdist[cc] = cm; cmask[cc] = m; ++cc; }
+                valid[c] = go && ci != kInvalidRef && ci < num_nodes;
+                if (valid[c]) ch[c] = load_ref_node(A.bvh4_ref, ci);
             }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool ok = valid[c] && !degenerate_box(ch[c]);
+                float ct = kInfT;
+                const bool chit = ok && ((hm >> sub) & 1u) != 0u && lane_aabb(r, ch[c].mn, ch[c].mx, best, ct);
+                const uint32_t m = quad_nibble(__ballot(chit), lane);
+                const float cm = quad_min(chit ? ct : kInfT);          // min over the packet's hit lanes (kInfT when none)
+                if (ok && m != 0u) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k == cc) { cidx[k] = node.c[c]; cdist[k] = cm; cmask[k] = m; }
+                    ++cc;
+                }
+            }
+        }
+        if (go && cc > 0) {
             int bi = 0;
-            for (int i = 1; i < cc; ++i) bi = (cdist[i] < cdist[bi]) ? i : bi;
-            if (bi != 0) {
-                const uint32_t ti = cidx[0]; const float td = cdist[0]; const uint32_t tm = cmask[0];
-                cidx[0] = cidx[bi]; cdist[0] = cdist[bi]; cmask[0] = cmask[bi];
-                cidx[bi] = ti; cdist[bi] = td; cmask[bi] = tm;
+#pragma unroll
+            for (int i = 1; i < 4; ++i) if (i < cc) bi = (cdist[i] < cdist[bi]) ? i : bi;
+            if (bi != 0) {                                   // the nearest child trades places with slot 0 (renderer.wgsl:320-330)
+#pragma unroll
+                for (int k = 1; k < 4; ++k) if (k == bi) {
+                    const uint32_t ti = cidx[0]; const float td = cdist[0]; const uint32_t tm = cmask[0];
+                    cidx[0] = cidx[k]; cdist[0] = cdist[k]; cmask[0] = cmask[k];
+                    cidx[k] = ti; cdist[k] = td; cmask[k] = tm;
+                }
             }
-            for (int i = cc - 1; i >= 0; --i)
-                if (sp + 1 < kStackMax) { ++sp; stack[sp] = cidx[i]; smask[sp] = (uint8_t)cmask[i]; }
+#pragma unroll
+            for (int i = 3; i >= 0; --i)                     // far -> near; a push beyond the 64 entries is dropped (renderer.wgsl:336-342)
+                if (i < cc && sp + 1 < kStackMax) { ++sp; if (sub == 0u) pstack[sp][pk] = make_uint2(cidx[i], cmask[i]); }
         }
     }
-    const F3 base = f3(0.9f, 0.7f, 0.3f);
-    const F3 L = light_dir();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (!(lanes & (1u << i))) continue;
-        const uint32_t px = bx + (i & 1), py = by + (i >> 1);
+    if (in_image) {                                          // renderer.wgsl:401-412
+        const F3 base = f3(0.9f, 0.7f, 0.3f);
+        const F3 L = light_dir();
         F3 col = f3(0.01f, 0.01f, 0.01f);
-        if (btri[i] != kInvalidRef) col = base * (0.15f + wmax(dot3(bn[i], L), 0.0f));
+        if (btri != kInvalidRef) col = base * (0.15f + wmax(dot3(bn, L), 0.0f));
         const size_t o = (size_t)py * A.width + px;
         A.out[o] = make_float4(col.x, col.y, col.z, 1.0f);
-        if (A.tri_ids) A.tri_ids[o] = btri[i];
+        if (A.tri_ids) A.tri_ids[o] = btri;
     }
 }
 
@@ -553,7 +586,7 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__
 // ------------------------------------------------------------------------------------
 hipError_t launch_render(const RenderArgs& A, int kmode, bool stats, hipStream_t stream) {
     if (kmode == PT_KMODE_PACKET) {
-        const dim3 grid((A.width + 31) / 32, (A.height + 31) / 32);   // 16x16 threads, 2x2 pixels each
+        const dim3 grid((A.width + 15) / 16, (A.height + 15) / 16);   // 256 lanes = 64 packets of 2 x 2 pixels = 16 x 16 pixels
         hipLaunchKernelGGL(render_packet_kernel, grid, dim3(256), 0, stream, A);
         return hipGetLastError();
     }
