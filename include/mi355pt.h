@@ -47,7 +47,7 @@ typedef enum PtStatus {
 
 /* renderer modes */
 enum {
-    PT_MODE_REFERENCE_PACKET = 0, /* literal renderer.wgsl:355-413: one thread per 2x2 packet, shared stack + lane masks */
+    PT_MODE_REFERENCE_PACKET = 0, /* literal renderer.wgsl:355-413: 2x2 ray packets with one shared stack + lane masks (a quad of lanes per packet) */
     PT_MODE_REFERENCE        = 1, /* same image, one ray per lane (identical except on exact-t ties) */
     PT_MODE_PATH             = 2  /* build-defined extension: spp, bounces, NEE, Russian roulette */
 };

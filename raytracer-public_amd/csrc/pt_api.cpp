@@ -849,7 +849,6 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     const bool sharded = count > 1 || (p->flags & PT_FLAG_COMPACT) != 0;
     if (sharded && p->mode == PT_MODE_REFERENCE_PACKET) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: the literal packet mode renders whole frames only");
     const bool stats = (p->flags & PT_FLAG_STATS) != 0;
-    if (stats && p->mode == PT_MODE_REFERENCE_PACKET) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: no counters in the literal packet mode");
 
     // A frame joins the open batch only if it has the same shape (resolution, spp, bounces, triangle count, tile share,
     // accumulation) and runs on the megakernel; anything else launches the open batch FIRST -- before any output buffer

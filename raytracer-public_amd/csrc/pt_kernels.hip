@@ -292,6 +292,10 @@ __device__ __forceinline__ float quad_min(float v) {
     return wmin(v, o);
 }
 
+// STATS: the oracle's packet-mode counters, counted once per packet (by the quad's first lane): node records examined (the root + every
+// valid child slot), getBVHNode4 calls as the reference makes them (one per pop + one per valid child: the double fetch), leaves whose
+// triangle was tested, dropped pushes, deepest stack.
+template <bool STATS>
 __global__ __launch_bounds__(256) void render_packet_kernel(const RenderArgs A) {
     __shared__ uint2 pstack[kStackMax][64];                  // [entry][packet of the block]: (node index, lane mask)
     const uint32_t lane = threadIdx.x & 63u, sub = threadIdx.x & 3u;
@@ -306,7 +310,11 @@ __global__ __launch_bounds__(256) void render_packet_kernel(const RenderArgs A) 
     const uint32_t lanes0 = quad_nibble(__ballot(in_image), lane);          // the packet's initial lane mask
     const uint32_t num_nodes = A.bvh4_ref[0];
     int sp = -1;
-    if (num_nodes != 0u && A.num_tris != 0u && lanes0 != 0u) { sp = 0; if (sub == 0u) pstack[0][pk] = make_uint2(0u, lanes0); }     // renderer.wgsl:224-233
+    uint32_t c_nodes = 0, c_fetch = 0, c_tris = 0, c_drops = 0, c_maxstack = 0;
+    if (num_nodes != 0u && A.num_tris != 0u && lanes0 != 0u) {     // renderer.wgsl:224-233
+        sp = 0; if (sub == 0u) pstack[0][pk] = make_uint2(0u, lanes0);
+        if (STATS) { c_nodes = 1; c_maxstack = 1; }
+    }
     // (one wavefront holds whole quads, so a packet's LDS accesses are ordered by its own wavefront: no barrier is needed)
     while (__ballot(sp >= 0) != 0ull) {
         const bool live = sp >= 0;
@@ -314,6 +322,7 @@ __global__ __launch_bounds__(256) void render_packet_kernel(const RenderArgs A) 
         if (live) { const uint2 e = pstack[sp][pk]; ni = e.x; lm = e.y; --sp; }
         PNode node;
         if (live) node = load_ref_node(A.bvh4_ref, ni);
+        if (STATS && live) ++c_fetch;
         bool go = live && !degenerate_box(node);             // renderer.wgsl:244-246
         float tmin = kInfT;
         const bool hit = go && ((lm >> sub) & 1u) != 0u && lane_aabb(r, node.mn, node.mx, best, tmin);
@@ -321,6 +330,7 @@ __global__ __launch_bounds__(256) void render_packet_kernel(const RenderArgs A) 
         go = go && hm != 0u;
         if (go && node.leaf) {
             if (node.tri < A.num_tris) {                     // renderer.wgsl:262-283
+                if (STATS) ++c_tris;
                 const float* tp = A.tris9 + (size_t)node.tri * 9;
                 const F3 v0 = f3(tp[0], tp[1], tp[2]), v1 = f3(tp[3], tp[4], tp[5]), v2 = f3(tp[6], tp[7], tp[8]);
                 const F3 e1 = v1 - v0, e2 = v2 - v0;
@@ -354,6 +364,7 @@ __global__ __launch_bounds__(256) void render_packet_kernel(const RenderArgs A) 
                 const uint32_t ci = node.c[c];
                 valid[c] = go && ci != kInvalidRef && ci < num_nodes;
                 if (valid[c]) ch[c] = load_ref_node(A.bvh4_ref, ci);
+                if (STATS && valid[c]) { ++c_fetch; ++c_nodes; }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -383,7 +394,11 @@ __global__ __launch_bounds__(256) void render_packet_kernel(const RenderArgs A) 
             }
 #pragma unroll
             for (int i = 3; i >= 0; --i)                     // far -> near; a push beyond the 64 entries is dropped (renderer.wgsl:336-342)
-                if (i < cc && sp + 1 < kStackMax) { ++sp; if (sub == 0u) pstack[sp][pk] = make_uint2(cidx[i], cmask[i]); }
+                if (i < cc) {
+                    if (sp + 1 < kStackMax) { ++sp; if (sub == 0u) pstack[sp][pk] = make_uint2(cidx[i], cmask[i]); }
+                    else if (STATS) ++c_drops;
+                }
+            if (STATS && (uint32_t)(sp + 1) > c_maxstack) c_maxstack = (uint32_t)(sp + 1);
         }
     }
     if (in_image) {                                          // renderer.wgsl:401-412
@@ -394,6 +409,14 @@ __global__ __launch_bounds__(256) void render_packet_kernel(const RenderArgs A) 
         const size_t o = (size_t)py * A.width + px;
         A.out[o] = make_float4(col.x, col.y, col.z, 1.0f);
         if (A.tri_ids) A.tri_ids[o] = btri;
+    }
+    if (STATS) {
+        if (in_image) { atomicAdd(&A.stats[0], 1ull); atomicAdd(&A.stats[6], 1ull); }      // one closest ray / sample per pixel of the image
+        if (sub == 0u) {                                                                   // per packet
+            atomicAdd(&A.stats[2], (unsigned long long)c_nodes); atomicAdd(&A.stats[3], (unsigned long long)c_tris);
+            atomicAdd(&A.stats[4], (unsigned long long)c_drops); atomicMax(&A.stats[5], (unsigned long long)c_maxstack);
+            atomicAdd(&A.stats[7], (unsigned long long)c_fetch);                           // node_fetches_ref: the reference's double fetch
+        }
     }
 }
 
@@ -587,7 +610,8 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__
 hipError_t launch_render(const RenderArgs& A, int kmode, bool stats, hipStream_t stream) {
     if (kmode == PT_KMODE_PACKET) {
         const dim3 grid((A.width + 15) / 16, (A.height + 15) / 16);   // 256 lanes = 64 packets of 2 x 2 pixels = 16 x 16 pixels
-        hipLaunchKernelGGL(render_packet_kernel, grid, dim3(256), 0, stream, A);
+        if (stats) hipLaunchKernelGGL(render_packet_kernel<true>, grid, dim3(256), 0, stream, A);
+        else       hipLaunchKernelGGL(render_packet_kernel<false>, grid, dim3(256), 0, stream, A);
         return hipGetLastError();
     }
     const uint32_t items = A.num_tiles * 64u;

@@ -72,12 +72,11 @@ def test_stack_overflow_drops_match_the_reference_semantics(rt, orc, ctx, levels
             kw = dict(mode=mode, spp=3, max_bounces=4, seed=5, frame=2)
             ref, _, ost = orc.render(orc.make_params(w, h, n, cam, quat, mode=OMODE[mode], spp=3, max_bounces=4, seed=5, frame=2), tris, bvh4)
             assert ost["stack_drops"] > 0 and ost["max_stack"] == 64          # the scene really overruns the stack
-            ctx.render(ctx.make_params(w, h, cam, quat, stats=(mode != 0), **kw))
+            ctx.render(ctx.make_params(w, h, cam, quat, stats=True, **kw))
             assert same_bits(ctx.read_radiance(), ref), (mode, cam)
-            if mode != 0:
-                st = ctx.stats()
-                for k in COUNTERS:
-                    assert st[k] == ost[k], (k, mode, cam)
+            st = ctx.stats()                    # mode 0: the packet's shared stack drops the same pushes as the reference's (one count per packet)
+            for k in COUNTERS:
+                assert st[k] == ost[k], (k, mode, cam)
         # the un-instrumented megakernel and the one-pixel-per-lane kernel drop the same pushes
         ref, _, ost = orc.render(orc.make_params(w, h, n, cam, quat, mode=orc_mod.MODE_PATH, spp=3, max_bounces=4, seed=5, frame=2), tris, bvh4)
         ctx.render(ctx.make_params(w, h, cam, quat, mode=rt.PT_MODE_PATH, spp=3, max_bounces=4, seed=5, frame=2))
@@ -110,12 +109,11 @@ def test_skipped_children_image_and_counters(rt, orc, ctx, kind):
         ref, _, ost = orc.render(op, tris, bvh4)
         base, _, bst = orc.render(op, tris, clean)
         changed = changed or ost["nodes_examined"] != bst["nodes_examined"]
-        ctx.render(ctx.make_params(w, h, cam, quat, mode=mode, spp=2, max_bounces=4, seed=9, stats=(mode != 0)))
+        ctx.render(ctx.make_params(w, h, cam, quat, mode=mode, spp=2, max_bounces=4, seed=9, stats=True))
         assert same_bits(ctx.read_radiance(), ref), mode
-        if mode != 0:
-            st = ctx.stats()
-            for k in COUNTERS:
-                assert st[k] == ost[k], (k, mode)
+        st = ctx.stats()
+        for k in COUNTERS:
+            assert st[k] == ost[k], (k, mode)
     assert changed                                                            # the planted children are on rays' paths
     ctx.render(ctx.make_params(w, h, cam, quat, mode=rt.PT_MODE_PATH, spp=2, max_bounces=4, seed=9, simple_kernel=True, stats=True))
     ref, _, ost = orc.render(orc.make_params(w, h, n, cam, quat, mode=orc_mod.MODE_PATH, spp=2, max_bounces=4, seed=9), tris, bvh4)
@@ -136,16 +134,15 @@ def test_degenerate_root_is_fetched_once_and_misses(rt, orc, ctx):
         ctx.set_bvh4(bvh4)
         for mode in (0, 1, 2):
             ref, _, ost = orc.render(orc.make_params(48, 32, 2, mode=OMODE[mode], spp=2, max_bounces=2), tris, bvh4)
-            ctx.render(ctx.make_params(48, 32, mode=mode, spp=2, max_bounces=2, stats=(mode != 0)))
+            ctx.render(ctx.make_params(48, 32, mode=mode, spp=2, max_bounces=2, stats=True))
             img = ctx.read_radiance()
             assert same_bits(img, ref)
             assert (img[..., 0] > 0.011).any() == expect_hits
-            if mode != 0:
-                st = ctx.stats()
-                for k in COUNTERS:
-                    assert st[k] == ost[k], (k, mode, expect_hits)
-                if not expect_hits:
-                    assert st["nodes_examined"] == st["rays_closest"]          # exactly the root, once per ray
+            st = ctx.stats()
+            for k in COUNTERS:
+                assert st[k] == ost[k], (k, mode, expect_hits)
+            if not expect_hits and mode != 0:
+                assert st["nodes_examined"] == st["rays_closest"]          # exactly the root, once per ray (mode 0: once per 2x2 packet)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -141,8 +141,18 @@ def test_literal_packet_mode_bit_exact(rt, orc, gpu_ctx, kind):
         cam, quat = CAMS[1]
         gpu_ctx.render(gpu_ctx.make_params(w, h, cam, quat, mode=rt.PT_MODE_REFERENCE_PACKET))
         img = gpu_ctx.read_radiance()
-        ref, _, _ = orc.render(orc.make_params(w, h, tris.size // 9, cam, quat, mode=orc_mod.MODE_PACKET), tris, bvh4)
+        ref, _, ost = orc.render(orc.make_params(w, h, tris.size // 9, cam, quat, mode=orc_mod.MODE_PACKET), tris, bvh4)
         assert same_bits(img, ref)
+        # the instrumented form: the same image, and the oracle's packet-mode counters -- incl. the reference's double node fetch
+        # (getBVHNode4 once per pop and once per child slot, renderer.wgsl:240, 292), which only this mode performs
+        import ctypes as C
+        gpu_ctx.render(gpu_ctx.make_params(w, h, cam, quat, mode=rt.PT_MODE_REFERENCE_PACKET, stats=True))
+        assert same_bits(gpu_ctx.read_radiance(), ref)
+        st = gpu_ctx.stats()
+        for k in ("rays_closest", "nodes_examined", "tris_tested", "stack_drops", "max_stack", "samples"):
+            assert st[k] == ost[k], (k, kind, w, h)
+        dbg = np.zeros(24, np.uint64); rt.lib.pt_debug_counters(gpu_ctx.h, dbg.ctypes.data_as(C.c_void_p))
+        assert int(dbg[7]) == ost["node_fetches_ref"]
 
 
 @pytest.mark.parametrize("kind,spp,bounces", [("tetra", 2, 3), ("soup", 3, 4), ("dragon", 4, 8)])
