@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Many launches per frame slot: tens of thousands of small path-traced frames without host waits (the drain consolidation's per-launch epoch runs
+through its 4,000-launch renewal in every slot), the same frame index at regular intervals compared bit for bit with the first rendering of it."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+rt = importlib.import_module("raytracer-public_amd")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
+ctx = rt.Context(0); ctx.set_triangles(rt.procedural_scene(0, 30000)); ctx.build_bvh()
+kw = dict(mode=rt.PT_MODE_PATH, spp=2, max_bounces=6, seed=4)
+ctx.render(ctx.make_params(256, 160, frame=7, **kw)); want = ctx.read_radiance().copy()
+t0 = time.time(); checks = 0
+for i in range(n):
+    ctx.render(ctx.make_params(256, 160, frame=1000 + i, **kw))
+    if i % 2500 == 2499:
+        ctx.render(ctx.make_params(256, 160, frame=7, **kw))
+        got = ctx.read_radiance()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "frame 7 differs after %d launches" % i
+        checks += 1
+        print("%d launches, %d checks ok, %.1f s" % (i + 1, checks, time.time() - t0), flush=True)
+ctx.synchronize()
+print("launch stress ok: %d launches, %d checks, %.1f s" % (n, checks, time.time() - t0))
