@@ -32,6 +32,14 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the entry points declared in this header are its whole dynamic symbol table
+ * (tests/test_host_build.py checks both directions against `nm -D`). */
+#if defined(__GNUC__)
+#define PT_API __attribute__((visibility("default")))
+#else
+#define PT_API
+#endif
+
 typedef struct PtContext PtContext;
 
 typedef enum PtStatus {
@@ -94,113 +102,113 @@ typedef struct PtStats {
 
 /* PathTracer.initialize() (PathTracer.js:97-173): picks the device, creates the stream and
  * the fixed-size buffers.  device_ordinal < 0 selects the current HIP device. */
-int  pt_create(int device_ordinal, PtContext** out);
-void pt_destroy(PtContext* ctx);
-const char* pt_last_error(const PtContext* ctx);
-const char* pt_version(void);
+PT_API int  pt_create(int device_ordinal, PtContext** out);
+PT_API void pt_destroy(PtContext* ctx);
+PT_API const char* pt_last_error(const PtContext* ctx);
+PT_API const char* pt_version(void);
 /* Issue all work of this context on a caller-owned hipStream_t (e.g. torch's current
  * stream) instead of the context's own stream.  NULL restores the own stream. */
-int  pt_set_stream(PtContext* ctx, void* hip_stream);
-int  pt_synchronize(PtContext* ctx);
+PT_API int  pt_set_stream(PtContext* ctx, void* hip_stream);
+PT_API int  pt_synchronize(PtContext* ctx);
 /* The hipStream_t the context currently issues on (its own non-blocking stream unless pt_set_stream
  * replaced it) -- e.g. to wrap it as torch.cuda.ExternalStream so collectives order after the render. */
-int  pt_get_stream(PtContext* ctx, void** hip_stream);
+PT_API int  pt_get_stream(PtContext* ctx, void** hip_stream);
 
 /* ---- host-side scene build (no GPU touched; the reference runs these in JS) ------------ */
 
 /* computeBVH2Sizing / computeBVH4Sizing (PathTracer.js:227-238) */
-int pt_compute_bvh2_sizing(uint32_t num_tris, uint32_t* num_nodes2, uint64_t* bytes);
-int pt_compute_bvh4_sizing(uint32_t num_nodes4, uint64_t* bytes);
+PT_API int pt_compute_bvh2_sizing(uint32_t num_tris, uint32_t* num_nodes2, uint64_t* bytes);
+PT_API int pt_compute_bvh4_sizing(uint32_t num_nodes4, uint64_t* bytes);
 /* buildMortonAndSort (PathTracer.js:427-481): outputs hold num_tris words each */
-int pt_morton_sort(const float* tris, uint32_t num_tris, uint32_t* morton_sorted, uint32_t* tri_index_sorted);
+PT_API int pt_morton_sort(const float* tris, uint32_t num_tris, uint32_t* morton_sorted, uint32_t* tri_index_sorted);
 /* collapseLBVH2ToBVH4 (PathTracer.js:506-667): out holds up to 1 + 8*(2N-1) words */
-int pt_collapse_lbvh2_to_bvh4(const uint32_t* bvh2, uint32_t num_tris, uint32_t* out, uint64_t out_words, uint32_t* num_nodes4);
+PT_API int pt_collapse_lbvh2_to_bvh4(const uint32_t* bvh2, uint32_t num_tris, uint32_t* out, uint64_t out_words, uint32_t* num_nodes4);
 /* BVH2 -> BVH4_wide promotion (tests/test.cpp:106-196): out holds 1 + 8*bvh2[0] words */
-int pt_bvh2_to_bvh4_wide(const uint32_t* bvh2, uint64_t bvh2_words, uint32_t* out, uint64_t out_words);
+PT_API int pt_bvh2_to_bvh4_wide(const uint32_t* bvh2, uint64_t bvh2_words, uint32_t* out, uint64_t out_words);
 /* data/BVH2.bin, data/BVH4_wide.bin: raw little-endian u32 dumps (src/server/api.js:27-31,
  * tests/test.cpp:16-33).  pt_file_read_u32 returns the word count through *words; call with
  * dst = NULL to query the size. */
-int pt_file_write_u32(const char* path, const uint32_t* src, uint64_t words);
-int pt_file_read_u32(const char* path, uint32_t* dst, uint64_t dst_words, uint64_t* words);
+PT_API int pt_file_write_u32(const char* path, const uint32_t* src, uint64_t words);
+PT_API int pt_file_read_u32(const char* path, uint32_t* dst, uint64_t dst_words, uint64_t* words);
 
 /* Deterministic procedural stand-in scenes (the reference's dragon.glb / Sponza are absent,
  * SURVEY.md 0.3).  kind 0 = "dragon-class" closed bumpy knot, kind 1 = "sponza-class"
  * interior.  Writes exactly num_tris triangles (9 f32 each), normalised to [-1,1]^3. */
-int pt_scene_procedural(uint32_t kind, uint32_t seed, uint32_t num_tris, float* tris_out);
+PT_API int pt_scene_procedural(uint32_t kind, uint32_t seed, uint32_t num_tris, float* tris_out);
 
 /* ---- device scene state ------------------------------------------------------------ */
 
 /* device.queue.writeBuffer(triangles) (PathTracer.js:679); N <= 932,067 in the reference
  * (32 MiB buffer, :140-143) -- no such cap here. */
-int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris);
+PT_API int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris);
 /* buildBVH (PathTracer.js:671-749): Morton codes + sort (:411-481), LBVH2 kernels (BVHBuilder.wgsl), greedy collapse to
  * BVH4 (:506-667) -- every step on the device, same BVH2 / BVH4 buffers bit for bit as the reference's CPU + WebGPU split
  * (the host entry points below mirror the JS steps one by one).  The bounds of the INTERNAL BVH2 nodes, which only a BVH2
  * read-back looks at, are filled in by the first pt_read_bvh2. */
-int pt_build_bvh(PtContext* ctx);
+PT_API int pt_build_bvh(PtContext* ctx);
 /* LBVH2 kernels only, from caller-supplied sorted codes (the two dispatches at
  * PathTracer.js:709-728); result stays on the device for pt_read_bvh2. */
-int pt_build_lbvh2(PtContext* ctx, const uint32_t* morton_sorted, const uint32_t* tri_index_sorted);
+PT_API int pt_build_lbvh2(PtContext* ctx, const uint32_t* morton_sorted, const uint32_t* tri_index_sorted);
 /* readBVH2 (PathTracer.js:485-502): copies min(bytes, buffer size) bytes */
-int pt_read_bvh2(PtContext* ctx, uint32_t* dst, uint64_t bytes);
+PT_API int pt_read_bvh2(PtContext* ctx, uint32_t* dst, uint64_t bytes);
 /* writeBuffer(BVH) (PathTracer.js:739-740): install a BVH4 buffer in the reference layout
  * (collapse output or BVH4_wide).  Validated: sizes, child indices, no node reachable twice. */
-int pt_set_bvh4(PtContext* ctx, const uint32_t* bvh4, uint64_t words);
+PT_API int pt_set_bvh4(PtContext* ctx, const uint32_t* bvh4, uint64_t words);
 /* load a BVH2 buffer (data/BVH2.bin) and collapse it like buildBVH does after readback */
-int pt_set_bvh2(PtContext* ctx, const uint32_t* bvh2, uint64_t words);
-int pt_read_bvh4(PtContext* ctx, uint32_t* dst, uint64_t bytes);
+PT_API int pt_set_bvh2(PtContext* ctx, const uint32_t* bvh2, uint64_t words);
+PT_API int pt_read_bvh4(PtContext* ctx, uint32_t* dst, uint64_t bytes);
 /* Build-defined extension for BASELINE config C1 (Cornell box: triangles + analytic spheres, no BVH):
  * n spheres as (x, y, z, r) f32 quadruples, used only by PT_FLAG_BRUTE_FORCE renders. */
-int pt_set_spheres(PtContext* ctx, const float* xyzr, uint32_t num_spheres);
-int pt_scene_info(PtContext* ctx, uint32_t* num_tris, uint32_t* num_nodes2, uint32_t* num_nodes4);
+PT_API int pt_set_spheres(PtContext* ctx, const float* xyzr, uint32_t num_spheres);
+PT_API int pt_scene_info(PtContext* ctx, uint32_t* num_tris, uint32_t* num_nodes2, uint32_t* num_nodes4);
 
 /* ---- the hot path ----------------------------------------------------------------- */
 
 /* PathTracer.render() compute pass (PathTracer.js:756-802 + renderer.wgsl:355-413).
  * Asynchronous on the context's stream; results are read with pt_read_radiance. */
-int pt_render(PtContext* ctx, const PtRenderParams* params);
+PT_API int pt_render(PtContext* ctx, const PtRenderParams* params);
 /* Batched submission (PT_MODE_PATH): queue `frames_per_launch` (1..256, default 1) consecutive pt_render calls of
  * the same shape and trace them with ONE persistent launch -- small frames (e.g. a 1/8 tile share of a
  * multi-GPU run) then fill the chip like a whole frame does.  A partial batch is launched by whatever
  * needs its result: pt_synchronize, any read-back, pt_compact_radiance / pt_deinterleave, scene changes.
  * Each frame still resolves into the output target that was current when it was submitted. */
-int pt_set_batch(PtContext* ctx, uint32_t frames_per_launch);
+PT_API int pt_set_batch(PtContext* ctx, uint32_t frames_per_launch);
 /* Launch a partially filled batch now (asynchronous, no host synchronisation). */
-int pt_flush(PtContext* ctx);
+PT_API int pt_flush(PtContext* ctx);
 /* Device time of the last pt_render's kernel(s), by hipEvents on the stream it ran on.
  * Synchronises the stream. */
-int pt_last_render_ms(PtContext* ctx, float* ms);
+PT_API int pt_last_render_ms(PtContext* ctx, float* ms);
 /* Per-launch kernel timing without host synchronisation inside a timed loop: after
  * pt_timing_begin(ctx, capacity) every pt_render records its own hipEvent pair (on the stream
  * the kernel is launched on) into a ring; pt_timing_collect synchronises once and returns the
  * elapsed milliseconds of the recorded launches (oldest first) and their count. */
-int pt_timing_begin(PtContext* ctx, uint32_t capacity);
-int pt_timing_collect(PtContext* ctx, float* ms, uint32_t capacity, uint32_t* count);
+PT_API int pt_timing_begin(PtContext* ctx, uint32_t capacity);
+PT_API int pt_timing_collect(PtContext* ctx, float* ms, uint32_t capacity, uint32_t* count);
 /* The same, plus when each recorded launch started relative to the first one (launches of consecutive batches overlap on the
  * context's side streams: the union of the [start, start + duration] intervals is the time the GPU was busy tracing). */
-int pt_timing_collect_spans(PtContext* ctx, float* start_ms, float* dur_ms, uint32_t capacity, uint32_t* count);
-int pt_get_stats(PtContext* ctx, PtStats* out);
+PT_API int pt_timing_collect_spans(PtContext* ctx, float* start_ms, float* dur_ms, uint32_t capacity, uint32_t* count);
+PT_API int pt_get_stats(PtContext* ctx, PtStats* out);
 /* Full-frame f32 RGBA W*H*4 (tile_count <= 1).  Synchronises. */
-int pt_read_radiance(PtContext* ctx, float* dst, uint64_t dst_floats);
+PT_API int pt_read_radiance(PtContext* ctx, float* dst, uint64_t dst_floats);
 /* rgba8unorm equivalent of the reference's outputTex (PathTracer.js:163-172) */
-int pt_read_rgba8(PtContext* ctx, uint8_t* dst, uint64_t dst_bytes);
+PT_API int pt_read_rgba8(PtContext* ctx, uint8_t* dst, uint64_t dst_bytes);
 /* tonemapper.wgsl:24-41 applied to the last frame: Reinhard, gamma 1/2.2, vertical flip;
  * from_rgba8 != 0 first quantises to rgba8unorm like the reference's texture. */
-int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t dst_bytes);
+PT_API int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t dst_bytes);
 
 /* ---- pixel-tile sharding across GPUs (one context per GPU / rank) ------------------ */
 
 /* Number of 8x8 tiles / pixels-slots this rank owns for a W x H frame split tile_count ways. */
-int pt_tile_layout(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count,
+PT_API int pt_tile_layout(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count,
                    uint32_t* num_tiles, uint64_t* compact_floats);
 /* The tile ids (ty * ceil(W/8) + tx) this rank owns, in the order of its compact buffer: slot s of the buffer holds tile ids[s]
  * (64 pixels, row-major inside the 8x8 tile).  ids may be NULL to ask for the count only; capacity in entries.  This is the list
  * pt_render uploads for the share -- callers that assemble or check compact buffers themselves take the order from here. */
-int pt_tile_ids(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count,
+PT_API int pt_tile_ids(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count,
                 uint32_t* ids, uint32_t capacity, uint32_t* num_tiles);
 /* Device pointer + size of this rank's compact radiance buffer (tile-major, 64 px per tile,
  * f32 RGBA) after a render with tile_count > 1: the send buffer of the RCCL gather. */
-int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats);
+PT_API int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats);
 /* Render tile-sharded frames straight into a caller-owned device buffer (e.g. a torch tensor
  * that is then handed to the RCCL gather) instead of the context's own compact buffer.
  * `floats` is the buffer's capacity.  The buffer that is current when a frame is submitted is that frame's
@@ -209,27 +217,27 @@ int pt_compact_radiance(PtContext* ctx, void** device_ptr, uint64_t* floats);
  * that was submitted while it was current has returned -- or until pt_buffer_busy says it is free.  device_ptr = NULL
  * restores the internal buffer, launches whatever is still queued for caller-owned targets AND waits for it: when the call
  * returns no frame targets a caller-owned buffer any more. */
-int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
+PT_API int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
 /* The same for whole frames (tile_count <= 1): render into a caller-owned row-major f32 RGBA device buffer of at least
  * width*height*4 floats instead of the context's own frame buffer, e.g. one buffer per frame of a batched launch so that
  * every frame stays available (frames of one launch that share a target leave only the last one's result, exactly as if they
  * had been rendered one after the other).  The read-backs read the target of the last frame.  Same lifetime rule as
  * pt_set_compact_buffer; NULL restores the internal buffer, launches what is still queued and waits for it. */
-int pt_set_output_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
+PT_API int pt_set_output_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
 /* *busy = 1 while a frame that is queued (pt_set_batch) or in flight (launched, not yet resolved) still targets an address inside
  * [device_ptr, device_ptr + bytes): the check to make before freeing or re-using a buffer that was handed to
  * pt_set_compact_buffer / pt_set_output_buffer.  Does not wait. */
-int pt_buffer_busy(PtContext* ctx, const void* device_ptr, uint64_t bytes, int* busy);
+PT_API int pt_buffer_busy(PtContext* ctx, const void* device_ptr, uint64_t bytes, int* busy);
 /* Rank 0: scatter `tile_count` gathered compact buffers (device memory, concatenated in rank
  * order, each padded to `stride_floats`) into the context's full-frame radiance buffer. */
-int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride_floats,
+PT_API int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride_floats,
                     uint32_t width, uint32_t height, uint32_t tile_count);
 /* The same for a gathered BATCH of frames in one launch: rank r's share of frame j sits at gathered + r * rank_stride_floats +
  * j * frame_stride_floats (what one gather of `num_frames` consecutive compact buffers per rank leaves on the root); frame j is
  * scattered to frames_out_device + j * out_stride_floats (row-major f32 RGBA, caller-owned).  frames_out_device = NULL: the
  * context's own frame buffer, which holds one frame -- only the last frame of the batch is scattered (the earlier ones would
  * be replaced by it).  The read-backs then read the last frame. */
-int pt_deinterleave_batch(PtContext* ctx, const void* gathered_device, uint64_t rank_stride_floats, uint64_t frame_stride_floats,
+PT_API int pt_deinterleave_batch(PtContext* ctx, const void* gathered_device, uint64_t rank_stride_floats, uint64_t frame_stride_floats,
                           uint32_t num_frames, uint32_t width, uint32_t height, uint32_t tile_count,
                           void* frames_out_device, uint64_t out_stride_floats);
 
@@ -248,28 +256,42 @@ enum {
                                       so the N > 1 logic can be exercised on a one-GPU machine */
 };
 /* device_ordinals = NULL: devices 0 .. num_devices-1; num_devices = 0: every visible device */
-int  pt_group_create(const int* device_ordinals, uint32_t num_devices, uint32_t transport, PtGroup** out);
-void pt_group_destroy(PtGroup* group);
-const char* pt_group_last_error(const PtGroup* group);
-int  pt_group_size(const PtGroup* group, uint32_t* num_members);
+PT_API int  pt_group_create(const int* device_ordinals, uint32_t num_devices, uint32_t transport, PtGroup** out);
+PT_API void pt_group_destroy(PtGroup* group);
+PT_API const char* pt_group_last_error(const PtGroup* group);
+PT_API int  pt_group_size(const PtGroup* group, uint32_t* num_members);
 /* The member context of a rank (borrowed: valid until pt_group_destroy), e.g. rank 0 for pt_read_bvh2 / pt_scene_info. */
-int  pt_group_context(PtGroup* group, uint32_t rank, PtContext** ctx);
+PT_API int  pt_group_context(PtGroup* group, uint32_t rank, PtContext** ctx);
 /* scene, replicated on every member: pt_set_triangles / pt_build_bvh / pt_set_bvh2 / pt_set_bvh4 */
-int  pt_group_set_triangles(PtGroup* group, const float* tris, uint32_t num_tris);
-int  pt_group_build_bvh(PtGroup* group);
-int  pt_group_set_bvh2(PtGroup* group, const uint32_t* bvh2, uint64_t words);
-int  pt_group_set_bvh4(PtGroup* group, const uint32_t* bvh4, uint64_t words);
+PT_API int  pt_group_set_triangles(PtGroup* group, const float* tris, uint32_t num_tris);
+PT_API int  pt_group_build_bvh(PtGroup* group);
+PT_API int  pt_group_set_bvh2(PtGroup* group, const uint32_t* bvh2, uint64_t words);
+PT_API int  pt_group_set_bvh4(PtGroup* group, const uint32_t* bvh4, uint64_t words);
 /* pt_set_batch for every member; the gather then moves one batch per collective */
-int  pt_group_set_batch(PtGroup* group, uint32_t frames_per_launch);
+PT_API int  pt_group_set_batch(PtGroup* group, uint32_t frames_per_launch);
 /* One frame over all members (tile_rank / tile_count of `params` are ignored).  Asynchronous. */
-int  pt_group_render(PtGroup* group, const PtRenderParams* params);
+PT_API int  pt_group_render(PtGroup* group, const PtRenderParams* params);
 /* Launch, gather and de-interleave what is queued (a partial batch, an accumulating sequence).  Asynchronous. */
-int  pt_group_flush(PtGroup* group);
-int  pt_group_synchronize(PtGroup* group);
+PT_API int  pt_group_flush(PtGroup* group);
+PT_API int  pt_group_synchronize(PtGroup* group);
 /* pt_read_radiance / pt_read_rgba8 / pt_read_tonemapped of the last gathered frame (rank 0).  Synchronise. */
-int  pt_group_read_radiance(PtGroup* group, float* dst, uint64_t dst_floats);
-int  pt_group_read_rgba8(PtGroup* group, uint8_t* dst, uint64_t dst_bytes);
-int  pt_group_read_tonemapped(PtGroup* group, int from_rgba8, uint8_t* dst, uint64_t dst_bytes);
+PT_API int  pt_group_read_radiance(PtGroup* group, float* dst, uint64_t dst_floats);
+PT_API int  pt_group_read_rgba8(PtGroup* group, uint8_t* dst, uint64_t dst_bytes);
+PT_API int  pt_group_read_tonemapped(PtGroup* group, int from_rgba8, uint8_t* dst, uint64_t dst_bytes);
+
+/* ---- diagnostics: NOT part of the drop-in surface -------------------------------------------------------------------------
+ * Exported for this repository's own tests and tools (tests/test_gpu_parity.py, tools/sweep.sh, tools/wave_timeline.py); a binding
+ * for the reference has no use for them and they may change between builds of the library. */
+/* Override one launch heuristic of this context ("GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "CONSOLIDATE", "SLOTS", "CULL",
+ * "STATSBATCH", "QUAD"); value 0xFFFFFFFF restores the measured default.  Launches the open batch first.  The same knobs are read
+ * from PT_TUNE_<NAME> once, when a context is created. */
+PT_API int pt_debug_set_tune(PtContext* ctx, const char* name, uint32_t value);
+/* Raw counter block (24 words) of the last PT_FLAG_STATS launch: PtStats order in [0..6], then the instrumented megakernel's own
+ * diagnostics (stack pushes by depth, longest path / ray in traversal steps, re-seated wavefronts, ...). */
+PT_API int pt_debug_counters(PtContext* ctx, unsigned long long* dst24);
+/* Per-wavefront timeline of the last PT_FLAG_STATS megakernel launch: 16 words per wavefront (begin / queue-dry / end ticks, loop
+ * counts, cycle shares); *n_waves = wavefronts written (<= max_waves). */
+PT_API int pt_debug_wave_times(PtContext* ctx, unsigned long long* dst, uint32_t max_waves, uint32_t* n_waves);
 
 #ifdef __cplusplus
 }

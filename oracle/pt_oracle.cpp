@@ -852,6 +852,8 @@ int orc_moller_trumbore(const float o[3], const float d[3], const float v0[3], c
     *t = h.t[0];
     return h.hit[0] ? 1 : 0;
 }
+// rotateVectorByQuat, renderer.wgsl:66-72 (quaternion xyzw)
+void orc_rotate_by_quat(const float v[3], const float q[4], float out[3]) { V3 r = rotate_by_quat(v3(v[0], v[1], v[2]), q); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 void orc_safe_inv_dir(const float d[3], float out[3]) { V3 r = safe_inv_dir(v3(d[0], d[1], d[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 
 float orc_rnd(uint32_t seed, uint32_t pixel, uint32_t sidx, uint32_t bounce, uint32_t dim) { return rnd(sample_key(seed, pixel, sidx), bounce, dim); }

@@ -41,16 +41,16 @@ struct DevBuf {
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto,
-             consolidate = kAuto, slots = kAuto, cull = kAuto, stats_batch = kAuto;
+             consolidate = kAuto, slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"CONSOLIDATE", &PtTune::consolidate}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}};
+            {"FILL", &PtTune::fill}, {"CONSOLIDATE", &PtTune::consolidate}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "CONSOLIDATE", "SLOTS", "CULL", "STATSBATCH"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "CONSOLIDATE", "SLOTS", "CULL", "STATSBATCH", "QUAD"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -330,6 +330,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     A.shade_threshold = PtTune::pick(ctx->tune.shade, PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD);
     // drain consolidation: only paths that bounce have ray boundaries to be handed over at
     A.consolidate = (A.ref_mode == 0u && A.max_bounces != 0u) ? PtTune::pick(ctx->tune.consolidate, PT_CONSOLIDATE) : 0u;
+    A.quad_live = std::min(16u, PtTune::pick(ctx->tune.quad, PT_QUAD_LIVE));     // 16 quads per wavefront
     A.simd_slots = ptk::kSimdSlots; A.simd_cap = ptk::kSimdCap;
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
     // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
@@ -1041,7 +1042,7 @@ int pt_get_stats(PtContext* ctx, PtStats* out) {
     return PT_OK;
 }
 
-/* diagnostics (not in the public header): override one launch heuristic of this context ("FLUSH", "PASSES", "SLOTS", ...;
+/* diagnostics (include/mi355pt.h, last section): override one launch heuristic of this context
  * value 0xFFFFFFFF restores the measured default).  Launches the open batch first. */
 int pt_debug_set_tune(PtContext* ctx, const char* name, uint32_t value) {
     if (int rc = bind(ctx)) return rc;
@@ -1052,14 +1053,14 @@ int pt_debug_set_tune(PtContext* ctx, const char* name, uint32_t value) {
     return PT_OK;
 }
 
-/* diagnostics (not in the public header): raw counter block of the last STATS launch */
+/* diagnostics: raw counter block of the last STATS launch */
 int pt_debug_counters(PtContext* ctx, unsigned long long* dst24) {
     if (int rc = bind(ctx)) return rc;
     PT_HIP(ctx, hipMemcpy(dst24, ctx->d_stats.ptr, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 
-/* diagnostics (not in the public header): per-wave timeline of the last STATS megakernel launch */
+/* diagnostics: per-wave timeline of the last STATS megakernel launch */
 int pt_debug_wave_times(PtContext* ctx, unsigned long long* dst, uint32_t max_waves, uint32_t* n_waves) {
     if (int rc = bind(ctx)) return rc;
     const uint32_t n = ctx->wave_times_n < max_waves ? ctx->wave_times_n : max_waves;

@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256) void tri_records_kernel(const float* __restric
     const F3 c = cross3(e1, e2);
     const float inv = 1.0f / sqrtf((c.x * c.x + c.y * c.y) + c.z * c.z);
     float4* r = rec + (size_t)t * 3;
-    r[0] = make_float4(v0.x, v0.y, v0.z, e1.x);
-    r[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-    r[2] = make_float4(e2.z, c.x * inv, c.y * inv, c.z * inv);
+    r[0] = make_float4(v0.x, e1.x, e2.x, c.x * inv);      // axis-major (pt_host.h::TriRecord): piece a = component a of v0, e1, e2, n
+    r[1] = make_float4(v0.y, e1.y, e2.y, c.y * inv);
+    r[2] = make_float4(v0.z, e1.z, e2.z, c.z * inv);
 }
 
 // ------------------------------------------------------------------------------------
@@ -287,10 +287,10 @@ __global__ __launch_bounds__(256) void wide_nodes_kernel(const uint32_t* __restr
         ref[s] = (cr[7] & kLeaf) ? (kLeaf | (3u * (tri < num_tris ? tri : num_tris))) : node_base16 + 4u * wide_index[c];     // packed references (pt_host.h)
     }
     uint4* o = wide + (size_t)wide_index[i] * 4;
-    o[0] = make_uint4(box[0], box[1], box[2], box[3]);
-    o[1] = make_uint4(box[4], box[5], box[6], box[7]);
-    o[2] = make_uint4(box[8], box[9], box[10], box[11]);
-    o[3] = make_uint4(ref[0], ref[1], ref[2], ref[3]);
+    o[0] = make_uint4(box[0], box[1], box[2], ref[0]);       // child-major (pt_host.h::WideNode): piece k = child k's box + reference
+    o[1] = make_uint4(box[3], box[4], box[5], ref[1]);
+    o[2] = make_uint4(box[6], box[7], box[8], ref[2]);
+    o[3] = make_uint4(box[9], box[10], box[11], ref[3]);
 }
 
 inline uint32_t blocks(uint32_t n) { return (n + 255u) / 256u; }

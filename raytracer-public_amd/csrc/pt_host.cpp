@@ -271,13 +271,14 @@ bool build_wide_bvh(const uint32_t* bvh4, uint64_t words, uint32_t num_tris, uin
         WideNode& wn = out.nodes[w];
         for (int s = 0; s < 4; ++s) {
             const uint32_t c = r[3 + s];
-            wn.box[s][0] = kEmptyBox0; wn.box[s][1] = kEmptyBox1; wn.box[s][2] = kEmptyBox2;   // the inverted box (+inf, -inf) no ray enters
-            wn.ref[s] = kInvalid;
+            WideNode::Child& ch = wn.child[s];
+            ch.box[0] = kEmptyBox0; ch.box[1] = kEmptyBox1; ch.box[2] = kEmptyBox2;   // the inverted box (+inf, -inf) no ray enters
+            ch.ref = kInvalid;
             if (c == kInvalid || c >= m) continue;
             const uint32_t* cr = rec(c);
-            if (box_degenerate(cr[0], cr[1], cr[2])) { wn.ref[s] = kDegenerate; continue; }   // renderer.wgsl:291: fetched, then skipped
-            wn.box[s][0] = cr[0]; wn.box[s][1] = cr[1]; wn.box[s][2] = cr[2];
-            wn.ref[s] = (cr[7] & kLeafFlag) ? packed_leaf_ref(cr[7] & 0x7fffffffu, num_tris) : node_base16 + 4u * wide_index[c];
+            if (box_degenerate(cr[0], cr[1], cr[2])) { ch.ref = kDegenerate; continue; }   // renderer.wgsl:291: fetched, then skipped
+            ch.box[0] = cr[0]; ch.box[1] = cr[1]; ch.box[2] = cr[2];
+            ch.ref = (cr[7] & kLeafFlag) ? packed_leaf_ref(cr[7] & 0x7fffffffu, num_tris) : node_base16 + 4u * wide_index[c];
         }
     }
     return true;
@@ -287,12 +288,14 @@ void build_tri_records(const float* tris, uint32_t n, TriRecord* out) {
     for (uint32_t t = 0; t < n; ++t) {
         const float* p = tris + size_t(t) * 9;
         TriRecord& r = out[t];
-        for (int k = 0; k < 3; ++k) { r.v0[k] = p[k]; r.e1[k] = p[3 + k] - p[k]; r.e2[k] = p[6 + k] - p[k]; }
-        const float cx = r.e1[1] * r.e2[2] - r.e1[2] * r.e2[1];
-        const float cy = r.e1[2] * r.e2[0] - r.e1[0] * r.e2[2];
-        const float cz = r.e1[0] * r.e2[1] - r.e1[1] * r.e2[0];
+        float e1[3], e2[3];
+        for (int k = 0; k < 3; ++k) { e1[k] = p[3 + k] - p[k]; e2[k] = p[6 + k] - p[k]; }
+        const float cx = e1[1] * e2[2] - e1[2] * e2[1];
+        const float cy = e1[2] * e2[0] - e1[0] * e2[2];
+        const float cz = e1[0] * e2[1] - e1[1] * e2[0];
         const float inv = 1.0f / std::sqrt((cx * cx + cy * cy) + cz * cz);
-        r.n[0] = cx * inv; r.n[1] = cy * inv; r.n[2] = cz * inv;
+        const float n[3] = {cx * inv, cy * inv, cz * inv};
+        for (int k = 0; k < 3; ++k) { r.axis[k][0] = p[k]; r.axis[k][1] = e1[k]; r.axis[k][2] = e2[k]; r.axis[k][3] = n[k]; }
     }
 }
 

@@ -25,11 +25,15 @@ bool collapse_to_bvh4(const uint32_t* bvh2, uint32_t num_tris, std::vector<uint3
 bool promote_to_bvh4_wide(const uint32_t* bvh2, uint64_t words, std::vector<uint32_t>& out, std::string& err);
 
 // ---- device layouts ----------------------------------------------
-// One 64-byte record per INTERNAL BVH4 node: the packed f16 boxes of its four children
-// (3 words each, reference packing) followed by four child references.
+// One 64-byte record per INTERNAL BVH4 node, child-major: four 16-byte pieces, piece k = child k's packed f16 box
+// (3 words, reference packing, renderer.wgsl:94-99) + its reference.  A lane that fetches the whole record issues four
+// dwordx4 loads (one ray per lane); the four lanes of a quad that share one ray fetch one piece each -- one 16-byte
+// request per lane, the quad covers the 64-byte line (the drain's quad mode, pt_megakernel.hip).
 struct WideNode {
-    uint32_t box[4][3];
-    uint32_t ref[4];   // kInvalid = empty slot; kDegenerate = examined, never entered; else a packed reference (below)
+    struct Child {
+        uint32_t box[3];
+        uint32_t ref;  // kInvalid = empty slot; kDegenerate = examined, never entered; else a packed reference (below)
+    } child[4];
 };
 static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 
@@ -55,8 +59,10 @@ struct WideBvh {
 bool build_wide_bvh(const uint32_t* bvh4, uint64_t words, uint32_t num_tris, uint32_t node_base16, WideBvh& out, std::string& err);
 
 // 48-byte triangle record: v0, e1 = v1-v0, e2 = v2-v0, n = normalize(cross(e1,e2)) -- the same
-// f32 operations renderer.wgsl:179-180,269 performs per visit, done once at upload.
-struct TriRecord { float v0[3], e1[3], e2[3], n[3]; };
+// f32 operations renderer.wgsl:179-180,269 performs per visit, done once at upload.  Axis-major: piece a (16 bytes) holds
+// component a of the four vectors, (v0[a], e1[a], e2[a], n[a]) -- three lanes of a quad that fetch one piece each hold the
+// triangle in structure-of-arrays form for the quad's Moller-Trumbore (pt_megakernel.hip).
+struct TriRecord { float axis[3][4]; };
 static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
 void build_tri_records(const float* tris, uint32_t n, TriRecord* out);
 

@@ -23,8 +23,14 @@
 #ifndef PT_SHADE_THRESHOLD
 #define PT_SHADE_THRESHOLD 16       // lanes waiting for a shade pass before one runs (or nothing traverses); 16 measured best in long launches, 8..16 equal for single frames (tools/sweep.sh SHADE)
 #endif
+#ifndef PT_QUAD
+#define PT_QUAD 1                  // 1: a wavefront with nothing left to start and at most PT_QUAD_LIVE paths goes on with one ray per quad of lanes (pt_megakernel.hip); 0: never; 2: quads from the first ray on (A/B builds)
+#endif
+#ifndef PT_QUAD_LIVE
+#define PT_QUAD_LIVE 16            // paths a wavefront may hold when it re-seats them (16 quads per wavefront)
+#endif
 #ifndef PT_CONSOLIDATE
-#define PT_CONSOLIDATE 1           // drain consolidation: once the queue is dry the wavefronts of a SIMD hand their paths to one collector (pt_megakernel.hip)
+#define PT_CONSOLIDATE (PT_QUAD == 1 ? 0 : 1)           // drain consolidation: once the queue is dry the wavefronts of a SIMD hand their paths to one collector (pt_megakernel.hip)
 #endif
 #ifndef PT_FILL_THRESHOLD
 #define PT_FILL_THRESHOLD 4        // hand out ready camera rays when this many lanes of a wavefront are without a path (a fetch from the ray buffer is cheap: 4 beats 8 by 2 %)
@@ -104,6 +110,7 @@ struct RenderArgs {
     float4*   simd_pool; uint32_t* simd_flags;
     uint32_t  simd_slots, simd_cap, simd_epoch, consolidate;
     uint32_t  shade_threshold, fill_threshold;
+    uint32_t  quad_live;        // re-seat the paths one per quad once the wavefront has nothing left to start and holds at most this many (0: never; needs consolidate == 0)
     // batched launch: frames[i] / outs[i] for i < num_frames; items of frame i are batches [i*batches_per_frame, ...)
     const FrameParams* frames; float4* const* outs;     // device arrays of the frame slot, filled by launch_frame_params
     uint32_t  num_frames, batches_per_frame;

@@ -43,7 +43,7 @@ __device__ __forceinline__ bool traverse(const RenderArgs& A, const Ray& r, floa
                 const float4* tp = (const float4*)arena_record(A, cur);
                 const float4 a = tp[0], b = tp[1], c = tp[2];
                 if (STATS) cnt.tris += 1;
-                const F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
+                const F3 v0 = f3(a.x, b.x, c.x), e1 = f3(a.y, b.y, c.y), e2 = f3(a.z, b.z, c.z);     // axis-major record (pt_host.h::TriRecord)
                 const F3 p = cross3(r.d, e2);                    // renderer.wgsl:185-205
                 const float det = dot3(e1, p);
                 if (!(fabsf(det) < kTriEps)) {
@@ -68,25 +68,27 @@ __device__ __forceinline__ bool traverse(const RenderArgs& A, const Ray& r, floa
             const uint4* np = arena_record(A, cur);
             const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             float t0, t1, t2, t3;
-            const bool h0 = (n3.x < kDegenerateRef) && slab(r, n0.x, n0.y, n0.z, best_t, t0);
-            const bool h1 = (n3.y < kDegenerateRef) && slab(r, n0.w, n1.x, n1.y, best_t, t1);
-            const bool h2 = (n3.z < kDegenerateRef) && slab(r, n1.z, n1.w, n2.x, best_t, t2);
-            const bool h3 = (n3.w < kDegenerateRef) && slab(r, n2.y, n2.z, n2.w, best_t, t3);
-            if (STATS) cnt.nodes += (n3.x != kInvalidRef) + (n3.y != kInvalidRef) + (n3.z != kInvalidRef) + (n3.w != kInvalidRef);
+            // child-major record (pt_host.h::WideNode): piece k = child k's box words + its reference
+            const uint32_t r0 = n0.w, r1 = n1.w, r2 = n2.w, r3 = n3.w;
+            const bool h0 = (r0 < kDegenerateRef) && slab(r, n0.x, n0.y, n0.z, best_t, t0);
+            const bool h1 = (r1 < kDegenerateRef) && slab(r, n1.x, n1.y, n1.z, best_t, t1);
+            const bool h2 = (r2 < kDegenerateRef) && slab(r, n2.x, n2.y, n2.z, best_t, t2);
+            const bool h3 = (r3 < kDegenerateRef) && slab(r, n3.x, n3.y, n3.z, best_t, t3);
+            if (STATS) cnt.nodes += (r0 != kInvalidRef) + (r1 != kInvalidRef) + (r2 != kInvalidRef) + (r3 != kInvalidRef);
             // nearest = first minimum in slot order (renderer.wgsl:315-318); first = first hit
             int nslot = -1, fslot = -1; float tn = kInfT, tf = 0.0f; uint32_t rn = kInvalidRef, rf = kInvalidRef;
-            if (h0) { nslot = 0; tn = t0; rn = n3.x; fslot = 0; tf = t0; rf = n3.x; }
-            if (h1) { if (nslot < 0 || t1 < tn) { nslot = 1; tn = t1; rn = n3.y; } if (fslot < 0) { fslot = 1; tf = t1; rf = n3.y; } }
-            if (h2) { if (nslot < 0 || t2 < tn) { nslot = 2; tn = t2; rn = n3.z; } if (fslot < 0) { fslot = 2; tf = t2; rf = n3.z; } }
-            if (h3) { if (nslot < 0 || t3 < tn) { nslot = 3; tn = t3; rn = n3.w; } if (fslot < 0) { fslot = 3; tf = t3; rf = n3.w; } }
+            if (h0) { nslot = 0; tn = t0; rn = r0; fslot = 0; tf = t0; rf = r0; }
+            if (h1) { if (nslot < 0 || t1 < tn) { nslot = 1; tn = t1; rn = r1; } if (fslot < 0) { fslot = 1; tf = t1; rf = r1; } }
+            if (h2) { if (nslot < 0 || t2 < tn) { nslot = 2; tn = t2; rn = r2; } if (fslot < 0) { fslot = 2; tf = t2; rf = r2; } }
+            if (h3) { if (nslot < 0 || t3 < tn) { nslot = 3; tn = t3; rn = r3; } if (fslot < 0) { fslot = 3; tf = t3; rf = r3; } }
             if (nslot < 0) {
                 need_pop = true;
             } else {
                 // pushes far -> near (renderer.wgsl:336-342); the slot the nearest child left holds the first hit
 #define PT_PUSH(REF, TMIN) do { if (sp < kStackMax) { stk[sp] = make_uint2((REF), __float_as_uint(TMIN)); ++sp; } else if (STATS) { cnt.drops += 1; } } while (0)
-                if (h3) { if (nslot == 3) { if (fslot != 3) PT_PUSH(rf, tf); } else if (fslot != 3) PT_PUSH(n3.w, t3); }
-                if (h2) { if (nslot == 2) { if (fslot != 2) PT_PUSH(rf, tf); } else if (fslot != 2) PT_PUSH(n3.z, t2); }
-                if (h1) { if (nslot == 1) { if (fslot != 1) PT_PUSH(rf, tf); } else if (fslot != 1) PT_PUSH(n3.y, t1); }
+                if (h3) { if (nslot == 3) { if (fslot != 3) PT_PUSH(rf, tf); } else if (fslot != 3) PT_PUSH(r3, t3); }
+                if (h2) { if (nslot == 2) { if (fslot != 2) PT_PUSH(rf, tf); } else if (fslot != 2) PT_PUSH(r2, t2); }
+                if (h1) { if (nslot == 1) { if (fslot != 1) PT_PUSH(rf, tf); } else if (fslot != 1) PT_PUSH(r1, t1); }
 #undef PT_PUSH
                 if (STATS) { const uint32_t depth = (uint32_t)sp + (sp < kStackMax ? 1u : 0u); if (depth > cnt.maxstack) cnt.maxstack = depth; }   // entries incl. the nearest child, if its push fitted
                 if (sp < kStackMax) cur = rn;          // the push of the nearest child would have fitted
@@ -117,7 +119,7 @@ __device__ __forceinline__ bool brute_trace(const RenderArgs& A, const Ray& r, f
         const float4* tp = A.tris + (size_t)ti * 3;
         const float4 a = tp[0], b = tp[1], c = tp[2];
         if (STATS) cnt.tris += 1;
-        const F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
+        const F3 v0 = f3(a.x, b.x, c.x), e1 = f3(a.y, b.y, c.y), e2 = f3(a.z, b.z, c.z);     // axis-major record (pt_host.h::TriRecord)
         const F3 p = cross3(r.d, e2);
         const float det = dot3(e1, p);
         if (fabsf(det) < kTriEps) continue;

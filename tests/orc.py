@@ -68,6 +68,7 @@ class Oracle:
         L.orc_slab.restype = C.c_int; L.orc_slab.argtypes = [F3, F3, F3, F3, C.c_float, F3]
         L.orc_moller_trumbore.restype = C.c_int; L.orc_moller_trumbore.argtypes = [F3, F3, F3, F3, F3, C.c_float, F3]
         L.orc_safe_inv_dir.argtypes = [F3, F3]
+        L.orc_rotate_by_quat.argtypes = [F3, F3, F3]
 
     # ---- scene build -------------------------------------------------
     def morton_sort(self, tris):
@@ -191,6 +192,13 @@ class Oracle:
         t = C.c_float()
         hit = self.lib.orc_moller_trumbore(*[_p(v, C.c_float) for v in a], C.c_float(best), C.byref(t))
         return bool(hit), np.float32(t.value)
+
+    def rotate_by_quat(self, v, q):
+        """rotateVectorByQuat (renderer.wgsl:66-72), quaternion xyzw -> rotated vector (f32)."""
+        v = np.ascontiguousarray(v, np.float32); q = np.ascontiguousarray(q, np.float32)
+        out = np.zeros(3, np.float32)
+        self.lib.orc_rotate_by_quat(_p(v, C.c_float), _p(q, C.c_float), _p(out, C.c_float))
+        return out
 
     def safe_inv_dir(self, d):
         d = np.ascontiguousarray(d, np.float32); out = np.zeros(3, np.float32)

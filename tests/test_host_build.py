@@ -12,12 +12,18 @@ def _u32(a):
 
 
 def test_library_exports_every_declared_symbol(rt):
+    """Both directions: every entry point include/mi355pt.h declares is exported, and the library's dynamic symbol table (`nm -D`)
+    holds nothing that the header does not declare (the library is linked with -fvisibility=hidden and a version script)."""
     hdr = open(os.path.join(os.path.dirname(rt.__file__), "..", "include", "mi355pt.h")).read()
-    declared = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"^PT_API [^;(]*?\b(pt_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
     assert declared == set(rt.EXPORTS), declared ^ set(rt.EXPORTS)
     for name in declared:
         assert hasattr(rt.lib, name), name
     assert b"gfx950" in rt.lib.pt_version()
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", rt.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def test_sizing(rt, golden_js):
