@@ -16,14 +16,20 @@ touched a GPU -- and exits with their status.  The frame is sharded by interleav
 xGMI (torch.distributed backend "nccl"), rank 0 de-interleaves them into the full frame.  The gather of launch b
 overlaps the trace of launch b+1.  Total work per step is fixed -> "scaling": "strong".
 
-Every run checks one TIMED frame against the CPU oracle on a fixed pixel grid (every 16th pixel in x and y, all samples,
+Every run checks one TIMED frame against the CPU oracle on a fixed pixel grid (every 4th pixel in x and y, all samples,
 bit for bit) and prints "verified": true; a mismatch ends the run with a non-zero status and no result line.
 
-The JSON line's `roofline` names the resource that bounds trace_paths_kernel (vector-instruction issue; DESIGN.md
-section 7), with the kernel's busy time measured live (union of the per-launch hipEvent intervals on the launch streams)
-and the per-frame counter totals taken from the rocprofv3 --pmc passes of THIS command committed under profiles/
-(tools/pmc_bench.sh).  The SURVEY 8d algorithmic byte rate is reported next to it, not as a fraction of a roof it does
-not touch: the scene is cache resident.
+The timed region (exactly K steps between barriers + synchronisations, max over ranks) is repeated --reps times (default 3,
+SURVEY 8d) after the warm-up; `value` / `ms_per_step` are the MEDIAN repetition, `ms_per_step_min_max` the spread.
+
+The JSON line's `roofline` carries the fractions of the four resources a gather-and-compute kernel can be bound by and names the
+largest as `bound` (the vector L1's request rate since round 3, vector-instruction issue next), each with the
+source of its peak (`peak_source`: "guide" = /opt/skills/guides/MI355X_MICROARCH.md, "probe" = measured by tools/probes/), with the
+kernel's busy time measured live (union of the per-launch hipEvent intervals on the launch streams, median repetition) and the
+per-frame counter totals taken from the rocprofv3 --pmc passes of THIS command committed under profiles/ (tools/pmc_bench.sh).  The
+SURVEY 8d algorithmic byte rate is reported next to it, not as a fraction of a roof it does not touch: the scene is cache resident.
+`configs` adds the whole-frame rate of C4 (sponza-class interior: no empty space, every camera ray hits) and rays / node tests per
+second for both, so the figure that does not lean on empty space travels with the line.
 """
 import argparse
 import hashlib
@@ -51,9 +57,9 @@ L2_PEAK_GBS, L2_LINE, HBM_PEAK_GBS = 34500.0, 128, 8000.0
 # the vector L1's request rate for this access pattern (every lane gathers its own 64-byte record with 4 x dwordx4): 217.7 G records/s x 4
 # requests, measured chip-wide by tools/probes/gather64.hip (profiles/r03_gather64_probe.txt, V0) -- 1.42 requests per cycle and CU
 L1_GATHER_PEAK_GREQ = 217.7 * 4
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")
 KERNEL_SOURCES = ["pt_megakernel.hip", "pt_device.h", "pt_kernels.h"]
-VERIFY_STEP = 16
+VERIFY_STEP = 4         # the timed frame is checked on every 4th pixel in x and y (1/16 of the frame, ~0.6 s of oracle time)
 SHARD_PIECES = 4        # launches a sharded run is cut into at least (tools/shard_schedule_sim.py)
 
 
@@ -208,7 +214,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--reps", type=int, default=3, help="repetitions of the timed region (value = the median one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C4 leg of the `configs` block")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--verify", action="store_true", help="kept for compatibility: the check against the oracle always runs")
@@ -272,7 +280,13 @@ def main():
     if sharded:
         stride = max(rt.tile_layout(width, height, r, world)[1] for r in range(world))
         compact = [torch.zeros(batch, stride, dtype=torch.float32, device="cuda") for _ in range(2)]
-        gathered = [torch.zeros(world, batch, stride, dtype=torch.float32, device="cuda") for _ in range(2)] if rank == 0 else [None, None]
+        # What travels are PACKED shares (mi355pt.h, pt_pack_shares): the rank's tiles inside the rectangle of tiles in which a camera ray can
+        # reach the scene at all, 12 bytes per pixel; rank 0 fills the rest of the frame with the camera-miss value.  Same camera every step,
+        # so one rectangle for the run -- a quarter of the compact buffers' bytes for this frame.
+        rect = ctx.traced_tile_rect(ctx.make_params(width, height, mode=rt.PT_MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED))
+        pstride = rt.packed_layout(width, height, world, rect)[1]
+        packed = [torch.zeros(batch, max(pstride, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        gathered = [torch.zeros(world, batch, max(pstride, 4), dtype=torch.float32, device="cuda") for _ in range(2)] if rank == 0 else [None, None]
         frames_full = torch.zeros(batch, height * width * 4, dtype=torch.float32, device="cuda") if rank == 0 else None     # the de-interleaved frames of one launch
         host_stage = backend != "nccl"   # rehearsal path (gloo): stage through host memory
         torch.cuda.synchronize()         # the zero fills ran on torch's default stream; everything below uses the context's
@@ -312,8 +326,8 @@ def main():
         if rank == 0:
             if host_stage:
                 gathered[slot][:, :nf].copy_(torch.stack(work.cpu_list))
-            # rank r's buffer of frame j sits at gathered[slot][r][j]: all nf frames are scattered by ONE launch, each into its own row-major frame
-            ctx.deinterleave_batch(gathered[slot].data_ptr(), batch * stride, stride, nf, width, height, world, frames_full.data_ptr(), height * width * 4)
+            # rank r's packed share of frame j sits at gathered[slot][r][j]: all nf frames are rebuilt by ONE launch, each into its own row-major frame
+            ctx.unpack_batch(gathered[slot].data_ptr(), batch * max(pstride, 4), max(pstride, 4), nf, width, height, world, rect, SPP, frames_full.data_ptr(), height * width * 4)
             last_frame["buf"] = nf - 1
 
     class _HostWork:                 # gloo rehearsal: synchronous host gather
@@ -326,12 +340,14 @@ def main():
         def wait(self):
             pass
 
-    def ship(slot, nf):              # the launch in compact[slot][:nf] has been submitted: gather it, finish the previous one
+    def ship(slot, nf):              # the launch in compact[slot][:nf] has been submitted: pack it behind its resolve, gather it, finish the previous one
+        if pstride:
+            ctx.pack_shares(compact[slot].data_ptr(), stride, nf, width, height, rank, world, rect, packed[slot].data_ptr(), max(pstride, 4))
         if host_stage:
-            work = _HostWork(compact[slot][:nf])
+            work = _HostWork(packed[slot][:nf])
         else:
             glist = [gathered[slot][r][:nf] for r in range(world)] if rank == 0 else None
-            work = dist.gather(compact[slot][:nf], glist, dst=0, async_op=True)
+            work = dist.gather(packed[slot][:nf], glist, dst=0, async_op=True)
         finish(pending[0])               # gather(b-1) has had the whole launch b to complete
         pending[0] = (work, slot, nf)
 
@@ -356,23 +372,31 @@ def main():
     p = params()
     with torch.cuda.stream(stream):
         run(args.warmup, args.steps, p, "warmup")
-    if sharded:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ctx.timing_begin(args.steps)
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        run(args.steps, 0, p, "timed")
-    torch.cuda.synchronize()
-    if sharded:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    k_start, k_ms = ctx.timing_collect_spans(args.steps)
-
-    if sharded:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- the timed region, `reps` times: exactly K steps between barriers + synchronisations, max over ranks; the median repetition is the result
+    reps = max(1, args.reps)
+    rep_elapsed, rep_spans = [], []
+    for rep in range(reps):
+        if sharded:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.timing_begin(args.steps)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            run(args.steps, 0, p, "timed" if rep == 0 else "timed-rep%d" % rep)      # the same K frame indices every repetition: the same work
+        torch.cuda.synchronize()
+        if sharded:
+            dist.barrier()
+        e = time.perf_counter() - t0
+        rep_spans.append(ctx.timing_collect_spans(args.steps))
+        if sharded:
+            t = torch.tensor([e], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        rep_elapsed.append(e)
+    order = sorted(range(reps), key=lambda i: rep_elapsed[i])
+    med = order[(reps - 1) // 2]                     # the median repetition (the lower one of an even count)
+    elapsed = rep_elapsed[med]
+    k_start, k_ms = rep_spans[med]
 
     # ---- the last timed frame against the CPU oracle (fixed pixel grid, every sample, bit for bit) -----------------------------
     verified = None
@@ -428,6 +452,42 @@ def main():
                      "ms_per_frame_solo": round(solo * 1e3, 4), "msamples_solo": round(width * height * SPP / solo / 1e6, 1),
                      "note": "pt_set_batch(1): one pt_render per frame as PathTracer.render() is called (src/main.js:70-74); pipelined = no host wait between frames, "
                              "solo = pt_synchronize after every frame; `value` above uses pt_set_batch, an extension the reference API does not have"}
+
+    # ---- the other single-GPU configuration: C4, a sponza-class interior (every camera ray hits, long paths: no empty space to lean on) --------
+    configs = None
+    if world == 1 and not args.no_configs and (width, height) == (WIDTH, HEIGHT):
+        def rates(st, seconds_per_frame):
+            return {"rays_per_s": round((st["rays_closest"] + st["rays_shadow"]) / seconds_per_frame, 1), "node_tests_per_s": round(st["nodes_examined"] / seconds_per_frame, 1),
+                    "tri_tests_per_s": round(st["tris_tested"] / seconds_per_frame, 1)}
+        c2_frame = {k: my_stats[k] / args.steps for k in my_stats}
+        configs = {"C2": {"ms_per_frame": round(elapsed / args.steps * 1e3, 4), "msamples": round(width * height * SPP * args.steps / elapsed / 1e6, 1),
+                          "rays_per_frame": int(c2_frame["rays_closest"] + c2_frame["rays_shadow"]), **rates(c2_frame, elapsed / args.steps)}}
+        c4 = rt.Context(device)
+        try:
+            c4_tris = rt.procedural_scene(rt.SCENE_SPONZA_CLASS, 262144, SCENE_SEED)
+            c4.set_triangles(c4_tris); c4.build_bvh()
+            cam4, quat4 = (0.55, -0.05, 0.05), (0.0, 0.6630, 0.0, 0.7486)
+            q = c4.make_params(width, height, cam4, quat4, mode=rt.PT_MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED, stats=True)
+            c4.render(q); st4 = c4.stats()
+            q = c4.make_params(width, height, cam4, quat4, mode=rt.PT_MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED)
+            c4.set_batch(8)
+            for i in range(8):
+                q.frame = 100 + i; c4.render(q)
+            c4.synchronize()
+            times = []
+            for rep in range(3):
+                t1 = time.perf_counter()
+                for i in range(8):
+                    q.frame = 200 + 8 * rep + i; c4.render(q)
+                c4.synchronize()
+                times.append((time.perf_counter() - t1) / 8)
+            t4 = sorted(times)[1]
+            configs["C4"] = {"workload": "sponza-class procedural interior, 262,144 triangles, camera inside, %dx%d, %d spp, %d bounces, 8 frames per launch, median of 3 launches" % (width, height, SPP, BOUNCES),
+                             "ms_per_frame": round(t4 * 1e3, 3), "msamples": round(width * height * SPP / t4 / 1e6, 1), "ms_per_frame_min_max": [round(min(times) * 1e3, 3), round(max(times) * 1e3, 3)],
+                             "rays_per_frame": int(st4["rays_closest"] + st4["rays_shadow"]), **rates(st4, t4),
+                             "algorithmic_GBps": round(algorithmic_bytes(st4) / t4 / 1e9, 1)}
+        finally:
+            c4.close()
 
     if rank == 0:
         log_path = os.environ.get("PT_BENCH_LAUNCH_LOG")
@@ -490,6 +550,8 @@ def main():
             "kernel_busy_ms": round(busy, 4), "kernel_busy_ms_per_frame": round(busy_per_frame, 5), "launches": int(len(k_ms)),
             "kernel_avg_launch_ms": round(float(np.mean(k_ms)), 4) if len(k_ms) else None, "frames_per_launch": frames_per_launch,
             "fractions": {k: round(v, 5) for k, v in fractions.items()},
+            "peak_source": {"l1_gather_requests": "probe (tools/probes/gather64.hip, profiles/r03_gather64_probe.txt: 871 G requests/s)", "valu_issue": "guide (SIMD-32: 2 cycles per wave64 instruction, 1,024 SIMDs, 2.4 GHz)",
+                            "l2_bandwidth": "guide (34.5 TB/s)", "hbm_fabric": "guide (8 TB/s)"},
             "fractions_over_builder_time": {k: round(v, 5) for k, v in fractions_builder.items()},
             "lane_utilisation": None if lane_util is None else round(lane_util, 4),
             "pmc": pmc_info,
@@ -508,16 +570,19 @@ def main():
         out = {
             "metric": "Msamples/sec @1920x1080 Stanford-Dragon-class, 4 spp, 8 bounces",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "reps": reps, "ms_per_step_min_max": [round(min(rep_elapsed) / args.steps * 1e3, 4), round(max(rep_elapsed) / args.steps * 1e3, 4)],
+            "ms_per_step_all": [round(e / args.steps * 1e3, 4) for e in rep_elapsed], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "verified": verified,
             "verified_how": "timed frame %d, every %dth pixel in x and y (all %d samples each), bit for bit against oracle/pt_oracle.cpp" % (args.steps - 1, VERIFY_STEP, SPP),
             "config": {"workload": "C2: dragon-class procedural closed mesh (%d tris, seed %d; dragon.glb absent), native LBVH2->BVH4, %dx%d, %d spp, %d bounces, camera (0,0,2.5) identity quat FOV 70, a new frame index (sample set) every step"
                                    % (NUM_TRIS, SCENE_SEED, width, height, SPP, BOUNCES),
                        "triangles": NUM_TRIS, "bvh4_nodes": ctx.scene_info()["numNodes4"], "width": width, "height": height,
                        "spp": SPP, "max_bounces": BOUNCES, "seed": SEED, "frames_per_launch": batch,
-                       "sharding": ("interleaved 8x8 tiles over %d GPUs, RCCL gather to rank 0" % world) if sharded else "single GPU, whole frame"},
+                       "sharding": ("interleaved 8x8 tiles over %d GPUs, RCCL gather of packed shares (tiles inside the traced rectangle %s, 12 B per pixel: %d of %d floats per frame and rank) to rank 0"
+                                    % (world, str(rect), pstride, stride)) if sharded else "single GPU, whole frame"},
             "roofline": roofline,
             "reference_call_shape": ref_shape,
+            "configs": configs,
         }
         if world == 1 and not args.no_cpu_baseline and (width, height) == (WIDTH, HEIGHT):
             out["cpu_baseline"] = cpu_baseline(tris, bvh4)

@@ -196,6 +196,27 @@ PT_API int pt_read_rgba8(PtContext* ctx, uint8_t* dst, uint64_t dst_bytes);
  * from_rgba8 != 0 first quantises to rgba8unorm like the reference's texture. */
 PT_API int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t dst_bytes);
 
+/* ---- checkpoint / resume of a progressive accumulation (PtRenderParams.accumulate) ------------------------------------------
+ * The reference has no accumulation; its only persistence is the raw BVH2 dump (src/server/api.js:27-31).  A
+ * progressive render of BASELINE configuration C5 (64 spp as 16 accumulated frames) is long enough to want the same: the running
+ * per-pixel state is ONE f32 RGBA buffer -- sums of the sample radiances in x, y, z, the sample count in w -- dumped and restored raw.
+ * Whole frame: W*H*4 floats, row-major like the radiance; a tile share (tile_count > 1 or PT_FLAG_COMPACT): tiles*64*4 floats,
+ * tile-major like the compact buffer (pt_tile_ids gives the order).  A restored context continues bit for bit: the next pt_render with
+ * accumulate = 1 and the same shape adds to the restored sums, with frame indices continuing where the dumped run stopped. */
+typedef struct PtAccumInfo {
+    uint32_t width, height;
+    uint32_t tile_rank, tile_count;   /* the share the sums cover (0 or 1 = every tile) */
+    uint32_t compact;                 /* 1: tile-major share layout, 0: whole frame, row-major */
+    uint32_t samples;                 /* samples per pixel accumulated so far (the w channel of every pixel) */
+    uint64_t floats;                  /* size of the dump; 0 = no running accumulation */
+} PtAccumInfo;
+PT_API int pt_accum_info(PtContext* ctx, PtAccumInfo* out);
+/* Launches what is queued and waits for it; dst holds at least info.floats floats. */
+PT_API int pt_read_accum(PtContext* ctx, float* dst, uint64_t dst_floats);
+/* Install running sums (the host array is copied during the call).  The scene must be set as for rendering; changing the scene
+ * afterwards restarts the accumulation, like it does for one that was rendered. */
+PT_API int pt_set_accum(PtContext* ctx, const PtAccumInfo* info, const float* src);
+
 /* ---- pixel-tile sharding across GPUs (one context per GPU / rank) ------------------ */
 
 /* Number of 8x8 tiles / pixels-slots this rank owns for a W x H frame split tile_count ways. */
@@ -224,9 +245,9 @@ PT_API int pt_set_compact_buffer(PtContext* ctx, void* device_ptr, uint64_t floa
  * had been rendered one after the other).  The read-backs read the target of the last frame.  Same lifetime rule as
  * pt_set_compact_buffer; NULL restores the internal buffer, launches what is still queued and waits for it. */
 PT_API int pt_set_output_buffer(PtContext* ctx, void* device_ptr, uint64_t floats);
-/* *busy = 1 while a frame that is queued (pt_set_batch) or in flight (launched, not yet resolved) still targets an address inside
- * [device_ptr, device_ptr + bytes): the check to make before freeing or re-using a buffer that was handed to
- * pt_set_compact_buffer / pt_set_output_buffer.  Does not wait. */
+/* *busy = 1 while a frame that is queued (pt_set_batch) or in flight (launched, not yet delivered) still writes into bytes that
+ * overlap [device_ptr, device_ptr + bytes) -- whichever kernel renders it, however many launches were submitted after it: the check
+ * to make before freeing or re-using a buffer that was handed to pt_set_compact_buffer / pt_set_output_buffer.  Does not wait. */
 PT_API int pt_buffer_busy(PtContext* ctx, const void* device_ptr, uint64_t bytes, int* busy);
 /* Rank 0: scatter `tile_count` gathered compact buffers (device memory, concatenated in rank
  * order, each padded to `stride_floats`) into the context's full-frame radiance buffer. */
@@ -240,6 +261,33 @@ PT_API int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t
 PT_API int pt_deinterleave_batch(PtContext* ctx, const void* gathered_device, uint64_t rank_stride_floats, uint64_t frame_stride_floats,
                           uint32_t num_frames, uint32_t width, uint32_t height, uint32_t tile_count,
                           void* frames_out_device, uint64_t out_stride_floats);
+
+/* Packed tile shares: what a sharded frame needs to ship.  Outside the rectangle of tiles in which a camera ray can reach the scene's
+ * root box at all, every pixel is the camera-miss value (renderer.wgsl:410) whatever is traced there -- two thirds of the tiles of the
+ * dragon-class frame -- and alpha is 1 everywhere.  So a rank packs only its tiles INSIDE the rectangle, 12 bytes per pixel (its tiles
+ * in row-major order, 64 x 3 floats each), the packed buffers are gathered, and rank 0 rebuilds the row-major frames: a quarter of the
+ * bytes of the compact buffers for that frame.  Non-accumulating frames only (a running sum outside the rectangle depends on history).
+ *
+ * pt_traced_tile_rect: rect = {tx0, ty0, tx1, ty1}, half-open, in 8x8 tiles -- the rectangle this context's launches trace for a frame
+ * with these parameters (the whole image when nothing can be left out); for several frames use the union. */
+PT_API int pt_traced_tile_rect(PtContext* ctx, const PtRenderParams* params, uint32_t rect[4]);
+/* Largest packed share over the ranks: tiles, and floats per frame (tiles * 192) -- the per-frame count of the gather. */
+PT_API int pt_packed_layout(uint32_t width, uint32_t height, uint32_t tile_count, const uint32_t rect[4], uint32_t* max_tiles, uint64_t* floats_per_frame);
+/* The tile ids (ty * ceil(W/8) + tx) of a rank's packed share, in the order of the packed buffer: slot s holds tile ids[s] as 64 pixels x
+ * (r, g, b).  ids may be NULL to ask for the count only.  (What pt_tile_ids is for the compact buffer.) */
+PT_API int pt_packed_tile_ids(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count, const uint32_t rect[4],
+                              uint32_t* ids, uint32_t capacity, uint32_t* num_tiles);
+/* Pack `num_frames` compact buffers of this rank (frame j at compact_device + j * frame_stride_floats, tile-major f32 RGBA as pt_render
+ * leaves them) into packed_device + j * packed_frame_stride_floats.  Asynchronous on the context's stream, behind the frames' resolve. */
+PT_API int pt_pack_shares(PtContext* ctx, const void* compact_device, uint64_t frame_stride_floats, uint32_t num_frames, uint32_t width, uint32_t height,
+                          uint32_t tile_rank, uint32_t tile_count, const uint32_t rect[4], void* packed_device, uint64_t packed_frame_stride_floats);
+/* Rank 0: rank r's packed share of frame j sits at gathered_device + r * rank_stride_floats + j * frame_stride_floats; frame j is rebuilt
+ * at frames_out_device + j * out_stride_floats (row-major f32 RGBA; NULL: the context's own frame buffer, last frame only, as
+ * pt_deinterleave_batch).  `spp` = samples per pixel of the frames (1 in the reference modes): the value outside the rectangle is the
+ * mean of spp camera-miss samples, formed exactly as the resolve pass forms it. */
+PT_API int pt_unpack_batch(PtContext* ctx, const void* gathered_device, uint64_t rank_stride_floats, uint64_t frame_stride_floats, uint32_t num_frames,
+                           uint32_t width, uint32_t height, uint32_t tile_count, const uint32_t rect[4], uint32_t spp,
+                           void* frames_out_device, uint64_t out_stride_floats);
 
 /* ---- one image from all GPUs of the node: a group of contexts inside ONE process ------------------------------
  *
@@ -289,7 +337,7 @@ PT_API int pt_debug_set_tune(PtContext* ctx, const char* name, uint32_t value);
 /* Raw counter block (24 words) of the last PT_FLAG_STATS launch: PtStats order in [0..6], then the instrumented megakernel's own
  * diagnostics (stack pushes by depth, longest path / ray in traversal steps, re-seated wavefronts, ...). */
 PT_API int pt_debug_counters(PtContext* ctx, unsigned long long* dst24);
-/* Per-wavefront timeline of the last PT_FLAG_STATS megakernel launch: 16 words per wavefront (begin / queue-dry / end ticks, loop
+/* Per-wavefront timeline of the last PT_FLAG_STATS megakernel launch: 24 words per wavefront (begin / queue-dry / end ticks, loop
  * counts, cycle shares); *n_waves = wavefronts written (<= max_waves). */
 PT_API int pt_debug_wave_times(PtContext* ctx, unsigned long long* dst, uint32_t max_waves, uint32_t* n_waves);
 

@@ -55,6 +55,11 @@ class PtStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class PtAccumInfo(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32),
+                ("compact", C.c_uint32), ("samples", C.c_uint32), ("floats", C.c_uint64)]
+
+
 # every symbol include/mi355pt.h declares (tests/test_host_build.py::test_library_exports_every_declared_symbol checks the header against this)
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_version", "pt_set_stream", "pt_get_stream", "pt_synchronize",
@@ -63,6 +68,8 @@ EXPORTS = [
     "pt_set_triangles", "pt_build_bvh", "pt_build_lbvh2", "pt_read_bvh2", "pt_set_bvh4", "pt_set_bvh2",
     "pt_read_bvh4", "pt_set_spheres", "pt_scene_info", "pt_render", "pt_last_render_ms", "pt_set_batch", "pt_flush", "pt_timing_begin", "pt_timing_collect", "pt_timing_collect_spans", "pt_set_compact_buffer", "pt_set_output_buffer", "pt_get_stats", "pt_read_radiance",
     "pt_read_rgba8", "pt_read_tonemapped", "pt_tile_layout", "pt_tile_ids", "pt_compact_radiance", "pt_deinterleave", "pt_deinterleave_batch", "pt_buffer_busy",
+    "pt_accum_info", "pt_read_accum", "pt_set_accum",
+    "pt_traced_tile_rect", "pt_packed_layout", "pt_packed_tile_ids", "pt_pack_shares", "pt_unpack_batch",
     "pt_group_create", "pt_group_destroy", "pt_group_last_error", "pt_group_size", "pt_group_context", "pt_group_set_triangles", "pt_group_build_bvh",
     "pt_group_set_bvh2", "pt_group_set_bvh4", "pt_group_set_batch", "pt_group_render", "pt_group_flush", "pt_group_synchronize", "pt_group_read_radiance",
     "pt_group_read_rgba8", "pt_group_read_tonemapped",
@@ -167,6 +174,22 @@ def tile_layout(width, height, rank, count):
     nt, fl = C.c_uint32(), C.c_uint64()
     _check(lib.pt_tile_layout(C.c_uint32(width), C.c_uint32(height), C.c_uint32(rank), C.c_uint32(count), C.byref(nt), C.byref(fl)))
     return nt.value, fl.value
+
+
+def packed_layout(width, height, count, rect):
+    """(largest packed share over the ranks in tiles, floats per frame of the gather) for the tile rectangle rect = (tx0, ty0, tx1, ty1)."""
+    r = (C.c_uint32 * 4)(*rect); mt, fl = C.c_uint32(), C.c_uint64()
+    _check(lib.pt_packed_layout(C.c_uint32(width), C.c_uint32(height), C.c_uint32(count), r, C.byref(mt), C.byref(fl)))
+    return mt.value, fl.value
+
+
+def packed_tile_ids(width, height, rank, count, rect):
+    """Tile ids of the rank's packed share (its tiles inside rect), in packed-buffer order."""
+    r = (C.c_uint32 * 4)(*rect); n = C.c_uint32()
+    _check(lib.pt_packed_tile_ids(C.c_uint32(width), C.c_uint32(height), C.c_uint32(rank), C.c_uint32(count), r, None, C.c_uint32(0), C.byref(n)))
+    ids = np.zeros(max(n.value, 1), np.uint32)
+    _check(lib.pt_packed_tile_ids(C.c_uint32(width), C.c_uint32(height), C.c_uint32(rank), C.c_uint32(count), r, _p(ids, C.c_uint32), C.c_uint32(ids.size), C.byref(n)))
+    return ids[: n.value]
 
 
 def tile_ids(width, height, rank, count):
@@ -342,6 +365,40 @@ class Context:
         self._ck(lib.pt_deinterleave_batch(self.h, C.c_void_p(gathered_device_ptr), C.c_uint64(rank_stride_floats), C.c_uint64(frame_stride_floats), C.c_uint32(num_frames),
                                            C.c_uint32(width), C.c_uint32(height), C.c_uint32(tile_count), C.c_void_p(frames_out_ptr or None), C.c_uint64(out_stride_floats)))
         self._last = (width, height)
+
+    # ---- packed tile shares (what a sharded frame ships) ----
+    def traced_tile_rect(self, params):
+        r = (C.c_uint32 * 4)()
+        self._ck(lib.pt_traced_tile_rect(self.h, C.byref(params), r))
+        return tuple(int(v) for v in r)
+
+    def pack_shares(self, compact_ptr, frame_stride_floats, num_frames, width, height, tile_rank, tile_count, rect, packed_ptr, packed_frame_stride_floats):
+        self._ck(lib.pt_pack_shares(self.h, C.c_void_p(compact_ptr), C.c_uint64(frame_stride_floats), C.c_uint32(num_frames), C.c_uint32(width), C.c_uint32(height),
+                                    C.c_uint32(tile_rank), C.c_uint32(tile_count), (C.c_uint32 * 4)(*rect), C.c_void_p(packed_ptr), C.c_uint64(packed_frame_stride_floats)))
+
+    def unpack_batch(self, gathered_ptr, rank_stride_floats, frame_stride_floats, num_frames, width, height, tile_count, rect, spp, frames_out_ptr=0, out_stride_floats=0):
+        self._ck(lib.pt_unpack_batch(self.h, C.c_void_p(gathered_ptr), C.c_uint64(rank_stride_floats), C.c_uint64(frame_stride_floats), C.c_uint32(num_frames),
+                                     C.c_uint32(width), C.c_uint32(height), C.c_uint32(tile_count), (C.c_uint32 * 4)(*rect), C.c_uint32(spp),
+                                     C.c_void_p(frames_out_ptr or None), C.c_uint64(out_stride_floats)))
+        self._last = (width, height)
+
+    # ---- checkpoint / resume of a progressive accumulation ----
+    def accum_info(self):
+        info = PtAccumInfo()
+        self._ck(lib.pt_accum_info(self.h, C.byref(info)))
+        return info
+
+    def read_accum(self):
+        """(PtAccumInfo, raw f32 dump: per-pixel sums in xyz, sample count in w) of the running accumulation."""
+        info = self.accum_info()
+        out = np.zeros(int(info.floats), np.float32)
+        self._ck(lib.pt_read_accum(self.h, _p(out, C.c_float), C.c_uint64(out.size)))
+        return info, out
+
+    def set_accum(self, info, data):
+        data = np.ascontiguousarray(data, np.float32).reshape(-1)
+        assert data.size == info.floats
+        self._ck(lib.pt_set_accum(self.h, C.byref(info), _p(data, C.c_float)))
 
     def buffer_busy(self, device_ptr, nbytes):
         b = C.c_int()

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -41,16 +42,16 @@ struct DevBuf {
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto,
-             consolidate = kAuto, slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto;
+             slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"CONSOLIDATE", &PtTune::consolidate}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}};
+            {"FILL", &PtTune::fill}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "CONSOLIDATE", "SLOTS", "CULL", "STATSBATCH", "QUAD"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL", "STATSBATCH", "QUAD"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -76,7 +77,7 @@ struct PtContext {
     pt::WideBvh wide_meta;           // root info; nodes vector emptied after upload
 
     DevBuf<float> d_tris9;           // reference layout
-    // One arena for the two record arrays the traversal gathers from: [triangle records, 48 B each, padded to a multiple of
+    // One arena for the two record arrays the traversal gathers from: [triangle records, 64 B each, padded to a multiple of
     // 64 B | wide nodes, 64 B each]: one allocation, one base address, 32-bit byte offsets reach both kinds.
     DevBuf<uint4> d_scene; uint64_t node_off = 0, node_cap = 0; uint32_t scene_tris = 0;
     float4* trirec() const { return (float4*)d_scene.ptr; }
@@ -97,14 +98,11 @@ struct PtContext {
     struct FrameSlot {
         hipStream_t side = nullptr; hipEvent_t resolved = nullptr, done = nullptr; bool used = false;
         DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<uint4> rays;
-        // drain consolidation: per-SIMD state words / published heads / hardware-key table (one allocation), record rings, flags; launches of the slot so far
-        DevBuf<unsigned long long> simd_ctl; DevBuf<float4> simd_pool; DevBuf<uint32_t> simd_flags; uint32_t simd_launches = 0;
         // owned-tile slots that the launch in this slot traces (the others are culled: every camera ray misses the root box)
         DevBuf<uint32_t> trace_slots; uint32_t* h_trace = nullptr; size_t h_trace_cap = 0; hipEvent_t trace_copied = nullptr;
         uint32_t cull_key[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t num_trace_tiles = 0; bool cull_valid = false;
         DevBuf<ptk::FrameParams> frame_params; DevBuf<float4*> frame_outs;      // per-frame parameters / targets of the launch in this slot
         const void* primed_ptr = nullptr; size_t primed_samples = 0;   // what the resident prefill covers
-        std::vector<float4*> launched_outs;                             // output targets of the launch last placed in this slot (pt_buffer_busy)
     };
     static constexpr int kMaxSlots = 16;
     FrameSlot slots[kMaxSlots]; int num_slots = 0; uint32_t next_slot = 0;
@@ -126,6 +124,14 @@ struct PtContext {
     uint64_t stats_culled = 0;          // pixel-samples of the last instrumented launch that were culled (counted as one root-box miss each)
     std::vector<hipEvent_t> ring;    // start/stop pairs recorded by pt_render while timing is on
     uint32_t ring_used = 0;
+    // pt_buffer_busy: the byte ranges that launches not yet known to be delivered write into.  Every launch appends its targets with its
+    // sequence number and records one event on the context's stream behind its last write (the resolve passes of consecutive launches
+    // are ordered there); ranges are dropped once their launch's event has completed -- whatever frame slot the launch ran in and
+    // however many launches were submitted after it.
+    struct InFlight { const char* lo; const char* hi; uint64_t seq; };
+    struct Fence { uint64_t seq; hipEvent_t ev; };
+    std::vector<InFlight> inflight; std::deque<Fence> fences; std::vector<hipEvent_t> fence_pool;
+    uint64_t launch_seq = 0;
 };
 
 namespace {
@@ -145,9 +151,44 @@ int bind(PtContext* ctx) {
     return PT_OK;
 }
 
-// Triangle records, then one all-zero record (what a leaf with an out-of-range triangle index points at: never hit), then padding
-// to a multiple of 64 B that also covers the 64-byte fetch of the last record.
-uint64_t tri_region_bytes(uint32_t num_tris) { return ((uint64_t(num_tris) * 48u + 48u + 64u + 63u) / 64u) * 64u; }
+// which pixels a running accumulation covers: tile rank (bits 0..11), tile count (12..23), compact tile-major layout (bit 31)
+uint32_t accum_share_key(uint32_t rank, uint32_t count, bool compact) { return (rank & 0xfffu) | ((count & 0xfffu) << 12) | (compact ? 0x80000000u : 0u); }
+
+// ---- pt_buffer_busy bookkeeping (PtContext::inflight) ----
+void prune_inflight(PtContext* ctx) {
+    uint64_t delivered = 0; bool any = false;
+    while (!ctx->fences.empty()) {
+        const hipError_t q = hipEventQuery(ctx->fences.front().ev);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }       // an answer, not an error: do not leave it behind for the launch checks
+        delivered = ctx->fences.front().seq; any = true;                     // complete (or failed: nothing will be written any more)
+        ctx->fence_pool.push_back(ctx->fences.front().ev); ctx->fences.pop_front();
+    }
+    if (any) ctx->inflight.erase(std::remove_if(ctx->inflight.begin(), ctx->inflight.end(), [&](const PtContext::InFlight& f) { return f.seq <= delivered; }), ctx->inflight.end());
+}
+void everything_delivered(PtContext* ctx) {         // after a host wait on the context's stream
+    for (auto& f : ctx->fences) ctx->fence_pool.push_back(f.ev);
+    ctx->fences.clear(); ctx->inflight.clear();
+}
+// the launch just submitted writes `bytes` bytes at each of targets[0..n): remembered until an event recorded here, behind it, completes
+int track_targets(PtContext* ctx, float4* const* targets, uint32_t n, size_t bytes) {
+    prune_inflight(ctx);
+    const uint64_t seq = ++ctx->launch_seq;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!targets[i]) continue;
+        bool dup = false;
+        for (uint32_t g = 0; g < i && !dup; ++g) dup = targets[g] == targets[i];
+        if (!dup) ctx->inflight.push_back({(const char*)targets[i], (const char*)targets[i] + bytes, seq});
+    }
+    hipEvent_t ev = nullptr;
+    if (!ctx->fence_pool.empty()) { ev = ctx->fence_pool.back(); ctx->fence_pool.pop_back(); }
+    else PT_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    PT_HIP(ctx, hipEventRecord(ev, ctx->stream));
+    ctx->fences.push_back({seq, ev});
+    return PT_OK;
+}
+
+// Triangle records (64 B each), then one all-zero record (what a leaf with an out-of-range triangle index points at: never hit).
+uint64_t tri_region_bytes(uint32_t num_tris) { return (uint64_t(num_tris) + 1u) * 64u; }
 
 // Room for `num_tris` triangle records and `nodes` wide nodes; triangle records that are already there survive a regrowth.
 int ensure_scene(PtContext* ctx, uint32_t num_tris, uint64_t nodes) {
@@ -156,16 +197,16 @@ int ensure_scene(PtContext* ctx, uint32_t num_tris, uint64_t nodes) {
     if (need >= 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "scene too large: triangle records and BVH nodes are addressed by 32-bit byte offsets (4 GiB)");
     if (ctx->d_scene.ptr && ctx->node_off == tri_bytes && ctx->node_cap >= nodes) {
         if (ctx->scene_tris != num_tris)      // another triangle count in the same region: the never-hit record moves
-            PT_HIP(ctx, hipMemset((char*)ctx->d_scene.ptr + uint64_t(num_tris) * 48u, 0, tri_bytes - uint64_t(num_tris) * 48u));
+            PT_HIP(ctx, hipMemset((char*)ctx->d_scene.ptr + uint64_t(num_tris) * 64u, 0, tri_bytes - uint64_t(num_tris) * 64u));
         ctx->scene_tris = num_tris; return PT_OK;
     }
     const uint64_t cap_nodes = nodes + nodes / 8u + 16u;
     uint4* fresh = nullptr;
     PT_HIP(ctx, hipMalloc((void**)&fresh, tri_bytes + (cap_nodes + 1u) * 64u));
     if (ctx->d_scene.ptr && ctx->scene_tris == num_tris && num_tris)          // the records of the current triangles move along
-        PT_HIP(ctx, hipMemcpy(fresh, ctx->d_scene.ptr, uint64_t(num_tris) * 48u, hipMemcpyDeviceToDevice));
+        PT_HIP(ctx, hipMemcpy(fresh, ctx->d_scene.ptr, uint64_t(num_tris) * 64u, hipMemcpyDeviceToDevice));
     if (ctx->d_scene.ptr) (void)hipFree(ctx->d_scene.ptr);
-    PT_HIP(ctx, hipMemset((char*)fresh + uint64_t(num_tris) * 48u, 0, tri_bytes - uint64_t(num_tris) * 48u));      // the never-hit record and the padding
+    PT_HIP(ctx, hipMemset((char*)fresh + uint64_t(num_tris) * 64u, 0, tri_bytes - uint64_t(num_tris) * 64u));      // the never-hit record
     ctx->d_scene.ptr = fresh; ctx->d_scene.cap = size_t((tri_bytes + (cap_nodes + 1u) * 64u) / 16u);
     ctx->node_off = tri_bytes; ctx->node_cap = cap_nodes; ctx->scene_tris = num_tris;
     return PT_OK;
@@ -328,10 +369,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         A.xcd_span = PtTune::pick(ctx->tune.xcd, work8_q >= 64u ? 1u : 0u) ? ((per + A.chunk_items - 1u) / A.chunk_items) * A.chunk_items : 0u;
     }
     A.shade_threshold = PtTune::pick(ctx->tune.shade, PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD);
-    // drain consolidation: only paths that bounce have ray boundaries to be handed over at
-    A.consolidate = (A.ref_mode == 0u && A.max_bounces != 0u) ? PtTune::pick(ctx->tune.consolidate, PT_CONSOLIDATE) : 0u;
     A.quad_live = std::min(16u, PtTune::pick(ctx->tune.quad, PT_QUAD_LIVE));     // 16 quads per wavefront
-    A.simd_slots = ptk::kSimdSlots; A.simd_cap = ptk::kSimdCap;
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
     // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
     // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small
@@ -363,15 +401,6 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         PT_HIP(ctx, s.samples.ensure(cap_samples));
         PT_HIP(ctx, s.spill.ensure(size_t(full_lanes) * size_t(64 - PT_SHORT_STACK)));
         PT_HIP(ctx, s.rays.ensure(size_t(full_lanes) * 3u));          // 64 ray records of 3 x uint4 per wavefront
-        if (A.consolidate) {
-            // [state words | published heads | hardware-key table + id counter] in one allocation (8-byte units), rings of 64 B records, one flag each
-            const size_t ctl_words64 = size_t(ptk::kSimdSlots) + (size_t(ptk::kSimdSlots) + ptk::kSimdKeys + 1u + 1u) / 2u + 1u;
-            const bool fresh = s.simd_flags.ptr == nullptr;
-            PT_HIP(ctx, s.simd_ctl.ensure(ctl_words64));
-            PT_HIP(ctx, s.simd_pool.ensure(size_t(ptk::kSimdSlots) * ptk::kSimdCap * 4u));
-            PT_HIP(ctx, s.simd_flags.ensure(size_t(ptk::kSimdSlots) * ptk::kSimdCap));
-            if (fresh) { PT_HIP(ctx, hipMemsetAsync(s.simd_flags.ptr, 0, size_t(ptk::kSimdSlots) * ptk::kSimdCap * sizeof(uint32_t), s.side)); s.simd_launches = 0; }
-        }
         PT_HIP(ctx, s.frame_params.ensure(std::max<size_t>(ctx->batch_size, nf))); PT_HIP(ctx, s.frame_outs.ensure(std::max<size_t>(ctx->batch_size, nf)));
         if (s.primed_ptr != (const void*)s.samples.ptr || s.primed_samples < cap_samples) {
             if (s.used) PT_HIP(ctx, hipStreamWaitEvent(s.side, s.resolved, 0));
@@ -382,20 +411,6 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(want_slots))];
     A.prime = stats ? 1u : 0u;                   // instrumented launches start from a freshly primed prefix
     A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.raybuf = sl.rays.ptr;
-    if (A.consolidate) {
-        A.simd_state = sl.simd_ctl.ptr;
-        A.simd_head = (uint32_t*)(sl.simd_ctl.ptr + ptk::kSimdSlots);
-        A.simd_ids = A.simd_head + ptk::kSimdSlots;
-        A.simd_pool = sl.simd_pool.ptr; A.simd_flags = sl.simd_flags.ptr;
-        // a flag is (epoch + absolute record index + 1): the epoch moves on by 2^20 per launch of the slot, so no stale flag of an earlier
-        // launch can pass for this one's; every 4,000 launches the flags are cleared and the count starts again
-        if (sl.simd_launches >= 4000u) {
-            if (sl.used) PT_HIP(ctx, hipStreamWaitEvent(sl.side, sl.resolved, 0));
-            PT_HIP(ctx, hipMemsetAsync(sl.simd_flags.ptr, 0, size_t(ptk::kSimdSlots) * ptk::kSimdCap * sizeof(uint32_t), sl.side));
-            sl.simd_launches = 0;
-        }
-        A.simd_epoch = (++sl.simd_launches) << 20;
-    }
     A.trace_slots = nullptr;
     if (cull) {
         // the list travels through a pinned staging buffer of the slot; it is rebuilt only when the rectangle (or the tile share) changes
@@ -417,7 +432,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     uint32_t stat_waves = 0;
     if (stats) {
         stat_waves = grid_lanes / 64u;
-        PT_HIP(ctx, ctx->d_wave_times.ensure(size_t(stat_waves) * 16u));
+        PT_HIP(ctx, ctx->d_wave_times.ensure(size_t(stat_waves) * ptk::kWaveTimeWords));
         A.wave_times = ctx->d_wave_times.ptr; ctx->wave_times_n = stat_waves;
     }
     // Dependencies: scene uploads are host-synchronous, so the trace only has to wait for the resolve
@@ -439,7 +454,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         // the counter blocks are zeroed on the stream the instrumented kernel runs on, behind everything that stream still has
         // to wait for; the previous reader (pt_get_stats / pt_debug_*) copied them synchronously
         PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 24 * sizeof(unsigned long long), sl.side));
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(stat_waves) * 16u * 8u, sl.side));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(stat_waves) * ptk::kWaveTimeWords * 8u, sl.side));
     }
     {   // per-frame parameters and targets into the slot's device arrays; a frame whose target a later frame of this launch
         // overwrites is marked (its result would not survive one-launch-per-frame rendering either)
@@ -451,7 +466,6 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
             F[i].accum_mode = (F[i].accum_mode & 0xffu) | (superseded ? 0x100u : 0u);
         }
         PT_HIP(ctx, ptk::launch_frame_params(F.data(), ctx->pending_outs.data(), nf, sl.frame_params.ptr, sl.frame_outs.ptr, sl.side));
-        sl.launched_outs.assign(ctx->pending_outs.begin(), ctx->pending_outs.begin() + nf);
         A.frames = sl.frame_params.ptr; A.outs = sl.frame_outs.ptr;
     }
     // timing ring: events tightly around the trace kernels on the stream they run on
@@ -460,6 +474,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.done, 0));
     PT_HIP(ctx, ptk::launch_resolve(A, ctx->stream));
     PT_HIP(ctx, hipEventRecord(sl.resolved, ctx->stream)); sl.used = true;
+    if (int rc = track_targets(ctx, ctx->pending_outs.data(), nf, (A.compact ? size_t(A.num_tiles) * 64u : size_t(A.width) * A.height) * sizeof(float4))) return rc;
     if (!ring) PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
     if (ring) ctx->ring_used += 2;
     ctx->timed = !ring;
@@ -527,7 +542,6 @@ void pt_destroy(PtContext* ctx) {
     if (ctx->h_word) (void)hipHostFree(ctx->h_word);
     for (auto& sl : ctx->slots) {
         sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.rays.release(); sl.trace_slots.release();
-        sl.simd_ctl.release(); sl.simd_pool.release(); sl.simd_flags.release();
         if (sl.h_trace) (void)hipHostFree(sl.h_trace);
         if (sl.trace_copied) (void)hipEventDestroy(sl.trace_copied); sl.frame_params.release(); sl.frame_outs.release();
         if (sl.resolved) (void)hipEventDestroy(sl.resolved);
@@ -535,6 +549,8 @@ void pt_destroy(PtContext* ctx) {
         if (sl.side) { (void)hipStreamSynchronize(sl.side); (void)hipStreamDestroy(sl.side); }
     }
     for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
+    for (auto& f : ctx->fences) (void)hipEventDestroy(f.ev);
+    for (hipEvent_t e : ctx->fence_pool) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -545,6 +561,7 @@ int pt_set_stream(PtContext* ctx, void* hip_stream) {
     if (int rc = bind(ctx)) return rc;
     if (int rc = flush_pending(ctx)) return rc;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    everything_delivered(ctx);
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     ctx->timed = false;
     return PT_OK;
@@ -560,6 +577,7 @@ int pt_synchronize(PtContext* ctx) {
     if (int rc = bind(ctx)) return rc;
     if (int rc = flush_pending(ctx)) return rc;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    everything_delivered(ctx);
     return PT_OK;
 }
 
@@ -641,7 +659,7 @@ int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris) {
     if (int rc = ensure_scene(ctx, num_tris, uint64_t(num_tris) + 16u)) return rc;
     if (num_tris) {
         PT_HIP(ctx, hipMemcpyAsync(ctx->d_tris9.ptr, tris, size_t(num_tris) * 36, hipMemcpyHostToDevice, ctx->stream));
-        PT_HIP(ctx, ptk::launch_tri_records(ctx->d_tris9.ptr, num_tris, ctx->trirec(), ctx->stream));   // 48 B records, DESIGN.md section 5
+        PT_HIP(ctx, ptk::launch_tri_records(ctx->d_tris9.ptr, num_tris, ctx->trirec(), ctx->stream));   // 64 B records, DESIGN.md section 5
     }
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->num_tris = num_tris;
@@ -848,7 +866,6 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     const uint32_t count = p->tile_count ? p->tile_count : 1;
     if (p->tile_rank >= count) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: tile_rank >= tile_count");
     const bool sharded = count > 1 || (p->flags & PT_FLAG_COMPACT) != 0;
-    if (sharded && p->mode == PT_MODE_REFERENCE_PACKET) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: the literal packet mode renders whole frames only");
     const bool stats = (p->flags & PT_FLAG_STATS) != 0;
 
     // A frame joins the open batch only if it has the same shape (resolution, spp, bounces, triangle count, tile share,
@@ -869,7 +886,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     A.width = p->width; A.height = p->height; A.focal = p->focal; A.aspect = p->aspect;
     std::memcpy(A.cam, p->cam_pos, 12); std::memcpy(A.quat, p->cam_quat, 16);
     A.num_tris = p->num_tris; A.frame = p->frame;
-    A.tri_gate3 = p->num_tris < ctx->num_tris ? 3u * p->num_tris : 0xFFFFFFFFu;
+    A.tri_gate = p->num_tris < ctx->num_tris ? 4u * p->num_tris : 0xFFFFFFFFu;
     A.root_ref = ctx->wide_meta.root_ref; std::memcpy(A.root_box, ctx->wide_meta.root_box, 12);
     A.root_degenerate = ctx->wide_meta.root_degenerate ? 1u : 0u;
     A.spheres = ctx->d_spheres.ptr; A.num_spheres = brute ? ctx->num_spheres : 0u; A.brute = brute ? 1u : 0u;
@@ -911,10 +928,11 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     if (p->mode == PT_MODE_PATH && p->accumulate) {
         DevBuf<float4>& acc = sharded ? ctx->d_compact_accum : ctx->d_accum;
         const size_t need = sharded ? size_t(A.num_tiles) * 64 : npx;
-        const bool cont = ctx->accum_count > 0 && ctx->accum_w == p->width && ctx->accum_h == p->height && ctx->accum_rank == (p->tile_rank | (count << 16)) && acc.cap >= need;
+        const uint32_t share_key = accum_share_key(p->tile_rank, count, sharded);
+        const bool cont = ctx->accum_count > 0 && ctx->accum_w == p->width && ctx->accum_h == p->height && ctx->accum_rank == share_key && acc.cap >= need;
         PT_HIP(ctx, acc.ensure(need));
         A.accum = acc.ptr; A.accumulate = cont ? 1u : 0u;
-        ctx->accum_w = p->width; ctx->accum_h = p->height; ctx->accum_rank = p->tile_rank | (count << 16);
+        ctx->accum_w = p->width; ctx->accum_h = p->height; ctx->accum_rank = share_key;
         ctx->accum_count = cont ? ctx->accum_count + p->spp : p->spp;
     } else {
         ctx->accum_count = 0;
@@ -964,6 +982,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
         PT_HIP(ctx, ptk::launch_render(A, kmode, stats, ctx->stream));
         PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        { float4* t = A.out; if (int rc = track_targets(ctx, &t, 1, (A.compact ? size_t(A.num_tiles) * 64u : npx) * sizeof(float4))) return rc; }
     }
     if (ring) ctx->ring_used += 2;
     ctx->timed = !ring;
@@ -1064,7 +1083,7 @@ int pt_debug_counters(PtContext* ctx, unsigned long long* dst24) {
 int pt_debug_wave_times(PtContext* ctx, unsigned long long* dst, uint32_t max_waves, uint32_t* n_waves) {
     if (int rc = bind(ctx)) return rc;
     const uint32_t n = ctx->wave_times_n < max_waves ? ctx->wave_times_n : max_waves;
-    if (n) PT_HIP(ctx, hipMemcpy(dst, ctx->d_wave_times.ptr, size_t(n) * 128u, hipMemcpyDeviceToHost));
+    if (n) PT_HIP(ctx, hipMemcpy(dst, ctx->d_wave_times.ptr, size_t(n) * ptk::kWaveTimeWords * 8u, hipMemcpyDeviceToHost));
     if (n_waves) *n_waves = n;
     return PT_OK;
 }
@@ -1104,6 +1123,50 @@ int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t ds
     PT_HIP(ctx, ptk::launch_tonemap(ctx->last_full, ctx->d_u32tmp.ptr, ctx->out_w, ctx->out_h, from_rgba8, ctx->stream));
     PT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_u32tmp.ptr, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+// ---- checkpoint / resume of a progressive accumulation -------------------------------------------------------------------------
+int pt_accum_info(PtContext* ctx, PtAccumInfo* out) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
+    if (!out) return fail(ctx, PT_ERR_INVALID_ARG, "pt_accum_info: null output");
+    std::memset(out, 0, sizeof(*out));
+    if (ctx->accum_count == 0) return PT_OK;                       // no running accumulation: floats = 0
+    out->width = ctx->accum_w; out->height = ctx->accum_h;
+    out->tile_rank = ctx->accum_rank & 0xfffu; out->tile_count = (ctx->accum_rank >> 12) & 0xfffu; out->compact = ctx->accum_rank >> 31;
+    out->samples = ctx->accum_count;
+    out->floats = out->compact ? uint64_t(pt::tile_count_of(out->width, out->height, out->tile_rank, out->tile_count)) * 256ull : uint64_t(out->width) * out->height * 4ull;
+    return PT_OK;
+}
+
+int pt_read_accum(PtContext* ctx, float* dst, uint64_t dst_floats) {
+    PtAccumInfo info;
+    if (int rc = pt_accum_info(ctx, &info)) return rc;
+    if (info.floats == 0) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_accum: no running accumulation (render with accumulate = 1 first)");
+    if (!dst || dst_floats < info.floats) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_accum: destination too small (pt_accum_info gives the size)");
+    const DevBuf<float4>& acc = info.compact ? ctx->d_compact_accum : ctx->d_accum;
+    PT_HIP(ctx, hipMemcpyAsync(dst, acc.ptr, info.floats * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_set_accum(PtContext* ctx, const PtAccumInfo* info, const float* src) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
+    if (!info || !src) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_accum: null argument");
+    const uint32_t count = info->tile_count ? info->tile_count : 1u;
+    if (info->width == 0 || info->height == 0 || info->width > 32768 || info->height > 32768 || info->tile_rank >= count || count > 0xfffu || info->samples == 0)
+        return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_accum: bad shape (resolution, tile share or a sample count of 0)");
+    const bool compact = info->compact != 0 || count > 1u;
+    const uint64_t need = compact ? uint64_t(pt::tile_count_of(info->width, info->height, info->tile_rank, count)) * 256ull : uint64_t(info->width) * info->height * 4ull;
+    if (info->floats != need) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_accum: `floats` does not match the shape (whole frame: W*H*4; tile share: tiles*64*4)");
+    DevBuf<float4>& acc = compact ? ctx->d_compact_accum : ctx->d_accum;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // nothing in flight still reads or writes the running sums
+    PT_HIP(ctx, acc.ensure(size_t(need / 4u)));
+    PT_HIP(ctx, hipMemcpyAsync(acc.ptr, src, need * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // the host array is not retained
+    ctx->accum_w = info->width; ctx->accum_h = info->height; ctx->accum_rank = accum_share_key(info->tile_rank, count, compact); ctx->accum_count = info->samples;
     return PT_OK;
 }
 
@@ -1175,6 +1238,86 @@ int pt_deinterleave_batch(PtContext* ctx, const void* gathered_device, uint64_t 
     return PT_OK;
 }
 
+// ---- packed tile shares: only the tiles a camera ray can reach the scene in travel, at 12 bytes per pixel ---------------------------
+int pt_traced_tile_rect(PtContext* ctx, const PtRenderParams* p, uint32_t rect[4]) {
+    if (!ctx || !p || !rect) return fail(ctx, PT_ERR_INVALID_ARG, "pt_traced_tile_rect: null argument");
+    if (p->width == 0 || p->height == 0 || p->width > 32768 || p->height > 32768) return fail(ctx, PT_ERR_INVALID_ARG, "pt_traced_tile_rect: bad resolution");
+    const uint32_t tiles_x = (p->width + pt::kTile - 1) / pt::kTile, tiles_y = (p->height + pt::kTile - 1) / pt::kTile;
+    rect[0] = 0; rect[1] = 0; rect[2] = tiles_x; rect[3] = tiles_y;                       // nothing can be left out: the whole image
+    const bool brute = (p->flags & PT_FLAG_BRUTE_FORCE) != 0;
+    if (brute || !ctx->have_bvh || ctx->wide_meta.root_ref == pt::kInvalid || ctx->wide_meta.root_degenerate || p->num_tris == 0u || ctx->tune.cull == 0u) return PT_OK;
+    ptk::FrameParams f; std::memset(&f, 0, sizeof(f));
+    std::memcpy(f.cam, p->cam_pos, 12); std::memcpy(f.quat, p->cam_quat, 16); f.focal = p->focal; f.aspect = p->aspect;
+    TileRect r;
+    if (root_box_rect(ctx->wide_meta, f, p->width, p->height, r)) { rect[0] = r.tx0; rect[1] = r.ty0; rect[2] = std::max(r.tx0, r.tx1); rect[3] = std::max(r.ty0, r.ty1); }
+    return PT_OK;
+}
+
+static bool rect_ok(const uint32_t rect[4], uint32_t width, uint32_t height) {
+    const uint32_t tiles_x = (width + pt::kTile - 1) / pt::kTile, tiles_y = (height + pt::kTile - 1) / pt::kTile;
+    return rect && rect[0] <= rect[2] && rect[1] <= rect[3] && rect[2] <= tiles_x && rect[3] <= tiles_y;
+}
+
+int pt_packed_layout(uint32_t width, uint32_t height, uint32_t tile_count, const uint32_t rect[4], uint32_t* max_tiles, uint64_t* floats_per_frame) {
+    if (tile_count == 0) tile_count = 1;
+    if (width == 0 || height == 0 || !rect_ok(rect, width, height)) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_packed_layout: bad rectangle");
+    uint32_t m = 0;
+    for (uint32_t r = 0; r < tile_count; ++r) m = std::max(m, pt::rect_tile_count_of(r, tile_count, rect));
+    if (max_tiles) *max_tiles = m;
+    if (floats_per_frame) *floats_per_frame = uint64_t(m) * 192ull;
+    return PT_OK;
+}
+
+int pt_packed_tile_ids(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count, const uint32_t rect[4], uint32_t* ids, uint32_t capacity, uint32_t* num_tiles) {
+    if (tile_count == 0) tile_count = 1;
+    if (tile_rank >= tile_count || width == 0 || height == 0 || !rect_ok(rect, width, height)) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_packed_tile_ids: bad arguments");
+    const uint32_t tiles_x = (width + pt::kTile - 1) / pt::kTile;
+    uint32_t n = 0;
+    for (uint32_t ty = rect[1]; ty < rect[3]; ++ty)
+        for (uint32_t tx = rect[0]; tx < rect[2]; ++tx)
+            if ((tx + ty) % tile_count == tile_rank) { if (ids) { if (n >= capacity) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_packed_tile_ids: destination too small"); ids[n] = ty * tiles_x + tx; } ++n; }
+    if (num_tiles) *num_tiles = n;
+    return PT_OK;
+}
+
+int pt_pack_shares(PtContext* ctx, const void* compact_device, uint64_t frame_stride_floats, uint32_t num_frames, uint32_t width, uint32_t height,
+                   uint32_t tile_rank, uint32_t tile_count, const uint32_t rect[4], void* packed_device, uint64_t packed_frame_stride_floats) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
+    if (tile_count == 0) tile_count = 1;
+    if (!compact_device || !packed_device || num_frames == 0 || (frame_stride_floats & 3) || width == 0 || height == 0 || tile_rank >= tile_count || !rect_ok(rect, width, height))
+        return fail(ctx, PT_ERR_INVALID_ARG, "pt_pack_shares: bad arguments");
+    const uint64_t own = uint64_t(pt::tile_count_of(width, height, tile_rank, tile_count)) * 256ull, packed = uint64_t(pt::rect_tile_count_of(tile_rank, tile_count, rect)) * 192ull;
+    if (num_frames > 1u && (frame_stride_floats < own || packed_frame_stride_floats < packed)) return fail(ctx, PT_ERR_INVALID_ARG, "pt_pack_shares: a frame stride is smaller than the share it holds");
+    PT_HIP(ctx, ptk::launch_pack_shares((const float4*)compact_device, frame_stride_floats / 4u, num_frames, (float*)packed_device, packed_frame_stride_floats, width, tile_rank, tile_count, rect, ctx->stream));
+    return PT_OK;
+}
+
+int pt_unpack_batch(PtContext* ctx, const void* gathered_device, uint64_t rank_stride_floats, uint64_t frame_stride_floats, uint32_t num_frames, uint32_t width, uint32_t height,
+                    uint32_t tile_count, const uint32_t rect[4], uint32_t spp, void* frames_out_device, uint64_t out_stride_floats) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = flush_pending(ctx)) return rc;
+    if (!gathered_device || tile_count == 0 || num_frames == 0 || (out_stride_floats & 3) || width == 0 || height == 0 || spp == 0 || !rect_ok(rect, width, height))
+        return fail(ctx, PT_ERR_INVALID_ARG, "pt_unpack_batch: bad arguments");
+    uint32_t max_tiles = 0; uint64_t share = 0;
+    if (int rc = pt_packed_layout(width, height, tile_count, rect, &max_tiles, &share)) return rc;
+    if (share > frame_stride_floats && num_frames > 1u) return fail(ctx, PT_ERR_INVALID_ARG, "pt_unpack_batch: frame stride smaller than a rank's packed share");
+    if (share + uint64_t(num_frames - 1u) * frame_stride_floats > rank_stride_floats && tile_count > 1u) return fail(ctx, PT_ERR_INVALID_ARG, "pt_unpack_batch: rank stride smaller than the frames of one rank");
+    const size_t npx = size_t(width) * height;
+    float4* out = (float4*)frames_out_device; uint64_t out_stride_px = out_stride_floats / 4u;
+    if (out) {
+        if (num_frames > 1u && out_stride_px < npx) return fail(ctx, PT_ERR_INVALID_ARG, "pt_unpack_batch: output stride smaller than a frame");
+    } else {                        // the context's own frame buffer holds one frame: the last of the batch (as pt_deinterleave_batch)
+        PT_HIP(ctx, ctx->d_out.ensure(npx));
+        out = ctx->d_out.ptr; out_stride_px = 0;
+        gathered_device = (const float*)gathered_device + size_t(num_frames - 1u) * frame_stride_floats;
+        num_frames = 1u;
+    }
+    PT_HIP(ctx, ptk::launch_unpack_frames((const float*)gathered_device, rank_stride_floats, frame_stride_floats, num_frames, out, out_stride_px, width, height, tile_count, rect, spp, ctx->stream));
+    ctx->out_w = width; ctx->out_h = height; ctx->last_full = out + size_t(num_frames - 1u) * out_stride_px;
+    return PT_OK;
+}
+
 int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride_floats, uint32_t width, uint32_t height, uint32_t tile_count) {
     return pt_deinterleave_batch(ctx, gathered_device, stride_floats, 0, 1, width, height, tile_count, nullptr, 0);
 }
@@ -1182,16 +1325,18 @@ int pt_deinterleave(PtContext* ctx, const void* gathered_device, uint64_t stride
 int pt_buffer_busy(PtContext* ctx, const void* device_ptr, uint64_t bytes, int* busy) {
     if (int rc = bind(ctx)) return rc;
     if (!busy) return fail(ctx, PT_ERR_INVALID_ARG, "pt_buffer_busy: null output");
-    const char* lo = (const char*)device_ptr; const char* hi = lo + bytes;
-    auto in_range = [&](const float4* t) { return device_ptr && (const char*)t >= lo && (const char*)t < hi; };
     *busy = 0;
-    for (uint32_t i = 0; i < ctx->pending && !*busy; ++i) if (in_range(ctx->pending_outs[i])) *busy = 1;        // queued, not launched yet
-    for (const auto& sl : ctx->slots) {
-        if (*busy || !sl.side || !sl.used || sl.launched_outs.empty()) continue;
-        const hipError_t q = hipEventQuery(sl.resolved);
-        (void)hipGetLastError();
-        if (q != hipErrorNotReady) continue;                                                                     // that launch has delivered its frames
-        for (const float4* t : sl.launched_outs) if (in_range(t)) { *busy = 1; break; }
+    if (!device_ptr || bytes == 0) return PT_OK;
+    const char* lo = (const char*)device_ptr; const char* hi = lo + bytes;
+    auto overlaps = [&](const char* t_lo, const char* t_hi) { return t_lo < hi && lo < t_hi; };
+    if (ctx->pending) {                                                                   // queued, not launched yet
+        const ptk::RenderArgs& Q = ctx->pendingA;
+        const size_t fb = (Q.compact ? size_t(Q.num_tiles) * 64u : size_t(Q.width) * Q.height) * sizeof(float4);
+        for (uint32_t i = 0; i < ctx->pending && !*busy; ++i) if (overlaps((const char*)ctx->pending_outs[i], (const char*)ctx->pending_outs[i] + fb)) *busy = 1;
+    }
+    if (!*busy) {
+        prune_inflight(ctx);                                                              // launched: busy until the launch's fence has completed
+        for (const auto& f : ctx->inflight) if (overlaps(f.lo, f.hi)) { *busy = 1; break; }
     }
     return PT_OK;
 }

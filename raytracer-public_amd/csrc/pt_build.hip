@@ -114,10 +114,11 @@ __global__ __launch_bounds__(256) void tri_records_kernel(const float* __restric
     const F3 e1 = f3(p[3] - p[0], p[4] - p[1], p[5] - p[2]), e2 = f3(p[6] - p[0], p[7] - p[1], p[8] - p[2]);
     const F3 c = cross3(e1, e2);
     const float inv = 1.0f / sqrtf((c.x * c.x + c.y * c.y) + c.z * c.z);
-    float4* r = rec + (size_t)t * 3;
-    r[0] = make_float4(v0.x, e1.x, e2.x, c.x * inv);      // axis-major (pt_host.h::TriRecord): piece a = component a of v0, e1, e2, n
-    r[1] = make_float4(v0.y, e1.y, e2.y, c.y * inv);
-    r[2] = make_float4(v0.z, e1.z, e2.z, c.z * inv);
+    float4* r = rec + (size_t)t * 4;
+    r[0] = make_float4(v0.x, e1.x, e2.x, 0.0f);           // pt_host.h::TriRecord: piece a = component a of v0, e1, e2; piece 3 = the normal
+    r[1] = make_float4(v0.y, e1.y, e2.y, 0.0f);
+    r[2] = make_float4(v0.z, e1.z, e2.z, 0.0f);
+    r[3] = make_float4(c.x * inv, c.y * inv, c.z * inv, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void wide_nodes_kernel(const uint32_t* __restr
         if (box_degenerate(w0, w1, w2)) { ref[s] = kDegenerateRef; continue; }   // fetched by the reference, entered by no ray
         box[3 * s] = w0; box[3 * s + 1] = w1; box[3 * s + 2] = w2;
         const uint32_t tri = cr[7] & 0x7fffffffu;
-        ref[s] = (cr[7] & kLeaf) ? (kLeaf | (3u * (tri < num_tris ? tri : num_tris))) : node_base16 + 4u * wide_index[c];     // packed references (pt_host.h)
+        ref[s] = (cr[7] & kLeaf) ? (kLeaf | (4u * (tri < num_tris ? tri : num_tris))) : node_base16 + 4u * wide_index[c];     // packed references (pt_host.h)
     }
     uint4* o = wide + (size_t)wide_index[i] * 4;
     o[0] = make_uint4(box[0], box[1], box[2], ref[0]);       // child-major (pt_host.h::WideNode): piece k = child k's box + reference

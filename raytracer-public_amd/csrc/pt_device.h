@@ -194,10 +194,10 @@ constexpr float kSkyAmbient = 0.15f;   // renderer.wgsl:352
 constexpr uint32_t kRRStart = 2;
 
 __device__ __forceinline__ F3 light_dir() { return normalize3(f3(1.0f, 1.5f, 1.0f)); }   // renderer.wgsl:349
-// triangle records are axis-major (pt_host.h::TriRecord): piece a = (v0[a], e1[a], e2[a], n[a])
+// triangle records (pt_host.h::TriRecord): 64 bytes, pieces 0..2 = (v0[a], e1[a], e2[a], 0) per axis a, piece 3 = the normal
 __device__ __forceinline__ F3 tri_normal(const RenderArgs& A, uint32_t ti) {
-    const float4* r = A.tris + (size_t)ti * 3;
-    return f3(r[0].w, r[1].w, r[2].w);
+    const float4 n = A.tris[(size_t)ti * 4 + 3];
+    return f3(n.x, n.y, n.z);
 }
 // Packed references (pt_host.h): a record's position in the scene arena in 16-byte units, leaf flag in bit 31 -- `ref << 4` is
 // the byte offset of the record whichever kind it is (the shift drops the flag).
@@ -205,8 +205,8 @@ __device__ __forceinline__ const uint4* arena_record(const RenderArgs& A, uint32
     return (const uint4*)((const char*)A.scene + (ref << 4));
 }
 __device__ __forceinline__ F3 tri_normal_ref(const RenderArgs& A, uint32_t leaf_ref) {
-    const uint4* r = arena_record(A, leaf_ref);
-    return f3(__uint_as_float(r[0].w), __uint_as_float(r[1].w), __uint_as_float(r[2].w));
+    const uint4 n = arena_record(A, leaf_ref)[3];
+    return f3(__uint_as_float(n.x), __uint_as_float(n.y), __uint_as_float(n.z));
 }
 
 

@@ -66,11 +66,13 @@ struct PtGroup {
     uint32_t width = 0, height = 0, batch = 1;
     uint64_t stride = 0;                          // floats per frame and rank (the largest share)
     std::vector<float*> compact[2];               // [set][rank]: batch * stride floats on that rank's GPU
-    float* gathered[2] = {nullptr, nullptr};      // rank 0's GPU: n * batch * stride floats
+    std::vector<float*> packed[2];                // [set][rank]: the same frames as packed shares (tiles inside the traced rectangle, 12 B per pixel): what travels
+    float* gathered[2] = {nullptr, nullptr};      // rank 0's GPU: n * batch * stride floats (packed shares need three quarters of it at most)
+    uint32_t rect[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // [set]: union of the traced tile rectangles of the frames submitted into the set
+    uint32_t spp[2] = {1, 1};                     // [set]: samples per pixel of those frames (the camera-miss mean outside the rectangle)
     hipEvent_t consumed[2] = {nullptr, nullptr};  // copy transport: rank 0 has de-interleaved what was last copied into gathered[set] (the peers' next copy into it waits for this)
     bool consumed_valid[2] = {false, false};
     std::vector<hipEvent_t> ready;                // copy transport: member r's share of the batch has arrived on rank 0
-    float* frames_out = nullptr; uint64_t frames_out_cap = 0;   // rank 0: the de-interleaved frames of a batch (batch * W * H * 4 floats), scattered by ONE launch
     uint32_t set = 0, queued = 0;                 // current buffer set, frames submitted into it
     bool accumulating = false, dirty = false;     // an accumulating sequence gathers only when an image is asked for
     bool have_frame = false;
@@ -91,10 +93,12 @@ void free_buffers(PtGroup* g) {
         for (uint32_t r = 0; r < g->compact[s].size(); ++r)
             if (g->compact[s][r]) { (void)hipSetDevice(g->devices[r]); (void)hipFree(g->compact[s][r]); }
         g->compact[s].clear();
+        for (uint32_t r = 0; r < g->packed[s].size(); ++r)
+            if (g->packed[s][r]) { (void)hipSetDevice(g->devices[r]); (void)hipFree(g->packed[s][r]); }
+        g->packed[s].clear();
         if (g->gathered[s]) { (void)hipSetDevice(g->devices[0]); (void)hipFree(g->gathered[s]); g->gathered[s] = nullptr; }
         g->consumed_valid[s] = false;
     }
-    if (g->frames_out) { (void)hipSetDevice(g->devices[0]); (void)hipFree(g->frames_out); g->frames_out = nullptr; g->frames_out_cap = 0; }
 }
 
 // (re)allocate the compact / gathered buffers for a frame shape; drains what is in flight first
@@ -112,37 +116,45 @@ int ensure_buffers(PtGroup* g, uint32_t width, uint32_t height) {
     g->stride = stride; g->width = width; g->height = height;
     const size_t bytes = size_t(g->batch) * stride * sizeof(float);
     for (int s = 0; s < 2; ++s) {
-        g->compact[s].assign(g->n, nullptr);
+        g->compact[s].assign(g->n, nullptr); g->packed[s].assign(g->n, nullptr);
         for (uint32_t r = 0; r < g->n; ++r) {
             G_HIP(g, hipSetDevice(g->devices[r]));
             G_HIP(g, hipMalloc((void**)&g->compact[s][r], bytes));
             G_HIP(g, hipMemset(g->compact[s][r], 0, bytes));
+            G_HIP(g, hipMalloc((void**)&g->packed[s][r], bytes));          // a packed share is at most 3/4 of the compact one (every tile inside the rectangle)
         }
         G_HIP(g, hipSetDevice(g->devices[0]));
         G_HIP(g, hipMalloc((void**)&g->gathered[s], bytes * g->n));
-    }
-    if (g->batch > 1u) {          // every frame of a batch is delivered: one row-major frame each on rank 0 (a batch of 1 lands in the context's own frame buffer)
-        G_HIP(g, hipSetDevice(g->devices[0]));
-        g->frames_out_cap = uint64_t(g->batch) * width * height * 4ull;
-        G_HIP(g, hipMalloc((void**)&g->frames_out, g->frames_out_cap * sizeof(float)));
     }
     g->set = 0; g->queued = 0;
     return PT_OK;
 }
 
-// Gather the `frames` frames submitted into buffer set `s` on rank 0 and de-interleave them with one launch (the last one stays the result
-// the read-backs see).  Only the frames that were submitted travel: rank r's share of frame j lands at gathered[s] + (r * frames + j) * stride.
+// Gather the `frames` frames submitted into buffer set `s` on rank 0 and de-interleave the last one (the result the read-backs see).  Only the frames that were submitted travel: rank r's share of frame j lands at gathered[s] + (r * frames + j) * stride.
 int gather_set(PtGroup* g, uint32_t s, uint32_t frames) {
     if (frames == 0) return PT_OK;
     for (uint32_t r = 0; r < g->n; ++r) G_PT(g, r, pt_flush(g->ctx[r]));          // a partly filled batch is launched now
-    const size_t count = size_t(frames) * g->stride;                              // floats per rank
+    // Plain frames travel as PACKED shares: only the tiles inside the traced rectangle, 12 bytes per pixel (mi355pt.h, pt_pack_shares) -- a
+    // quarter of the compact buffers for the dragon-class frame.  An accumulating sequence ships its compact buffer as it is (what a pixel
+    // outside the rectangle holds depends on the frames before).
+    const bool pack = !g->accumulating;
+    uint64_t pstride = g->stride;                                                 // floats per frame and rank that travel
+    if (pack) {
+        uint32_t mt = 0;
+        if (int rc = pt_packed_layout(g->width, g->height, g->n, g->rect[s], &mt, &pstride)) return gfail(g, rc, pt_last_error(nullptr));
+        for (uint32_t r = 0; r < g->n && pstride != 0; ++r)
+            G_PT(g, r, pt_pack_shares(g->ctx[r], g->compact[s][r], g->stride, frames, g->width, g->height, r, g->n, g->rect[s], g->packed[s][r], pstride));
+    }
+    std::vector<float*>& send = pack ? g->packed[s] : g->compact[s];
+    const size_t count = size_t(frames) * pstride;                                // floats per rank
+    if (count != 0) {
     if (g->transport == PT_GROUP_TRANSPORT_RCCL) {
         // one collective per batch: every member sends its compact buffer over its own xGMI link to the root.  (Rank 0's de-interleave of
         // the previous use of gathered[s] precedes this gather on its stream, and no peer's data lands before the root has posted it.)
         G_NCCL(g, g_rccl.GroupStart());
         for (uint32_t r = 0; r < g->n; ++r) {
             (void)hipSetDevice(g->devices[r]);                 // the documented single-process pattern: the rank's device is current when its call is issued
-            const ncclResult_t rc = g_rccl.Gather(g->compact[s][r], r == 0 ? g->gathered[s] : nullptr, count, kNcclFloat, 0, g->comm[r], g->stream[r]);
+            const ncclResult_t rc = g_rccl.Gather(send[r], r == 0 ? g->gathered[s] : nullptr, count, kNcclFloat, 0, g->comm[r], g->stream[r]);
             if (rc != 0) { (void)g_rccl.GroupEnd(); return gfail(g, PT_ERR_HIP, std::string("ncclGather: ") + g_rccl.GetErrorString(rc)); }
         }
         G_NCCL(g, g_rccl.GroupEnd());
@@ -154,14 +166,18 @@ int gather_set(PtGroup* g, uint32_t s, uint32_t frames) {
         for (uint32_t r = 0; r < g->n; ++r) {
             G_HIP(g, hipSetDevice(g->devices[r]));
             if (g->consumed_valid[s]) G_HIP(g, hipStreamWaitEvent(g->stream[r], g->consumed[s], 0));
-            G_HIP(g, hipMemcpyPeerAsync(g->gathered[s] + size_t(r) * count, g->devices[0], g->compact[s][r], g->devices[r], count * sizeof(float), g->stream[r]));
+            G_HIP(g, hipMemcpyPeerAsync(g->gathered[s] + size_t(r) * count, g->devices[0], send[r], g->devices[r], count * sizeof(float), g->stream[r]));
             G_HIP(g, hipEventRecord(g->ready[r], g->stream[r]));
         }
         G_HIP(g, hipSetDevice(g->devices[0]));
         for (uint32_t r = 1; r < g->n; ++r) G_HIP(g, hipStreamWaitEvent(g->stream[0], g->ready[r], 0));
     }
-    G_PT(g, 0, pt_deinterleave_batch(g->ctx[0], g->gathered[s], uint64_t(frames) * g->stride, g->stride, frames, g->width, g->height, g->n,
-                                     frames > 1u ? g->frames_out : nullptr, uint64_t(g->width) * g->height * 4ull));
+    }       // count != 0 (an empty rectangle: nothing travels, rank 0 fills the frame with the camera-miss value)
+    // The group's read-backs deliver the LAST frame of a batch (one image per render() is the reference's call shape, src/main.js:54-76;
+    // a batch exists to fill the GPUs): only that frame is scattered, into rank 0's own frame buffer -- the result then lives in memory the
+    // context owns, whatever happens to the group's buffers afterwards (pt_group_set_batch, a change of resolution).
+    if (pack) G_PT(g, 0, pt_unpack_batch(g->ctx[0], g->gathered[s], uint64_t(frames) * pstride, pstride, frames, g->width, g->height, g->n, g->rect[s], g->spp[s], nullptr, 0));
+    else G_PT(g, 0, pt_deinterleave_batch(g->ctx[0], g->gathered[s], uint64_t(frames) * g->stride, g->stride, frames, g->width, g->height, g->n, nullptr, 0));
     if (g->transport != PT_GROUP_TRANSPORT_RCCL) {
         G_HIP(g, hipSetDevice(g->devices[0]));
         G_HIP(g, hipEventRecord(g->consumed[s], g->stream[0])); g->consumed_valid[s] = true;
@@ -303,11 +319,22 @@ int pt_group_set_batch(PtGroup* g, uint32_t frames_per_launch) {
 
 int pt_group_render(PtGroup* g, const PtRenderParams* p) {
     if (!g || !p) return gfail(g, PT_ERR_INVALID_ARG, "pt_group_render: null argument");
-    if (p->mode == PT_MODE_REFERENCE_PACKET) return gfail(g, PT_ERR_INVALID_ARG, "pt_group_render: the literal packet mode renders whole frames only (use a plain context)");
     const bool accum = p->mode == PT_MODE_PATH && p->accumulate != 0;
-    if ((g->width != p->width || g->height != p->height || accum != g->accumulating) && (g->queued || g->dirty)) { if (int rc = flush_group(g)) return rc; }
+    const uint32_t spp = p->mode == PT_MODE_PATH ? p->spp : 1u;
+    if ((g->width != p->width || g->height != p->height || accum != g->accumulating || (g->queued && spp != g->spp[g->set])) && (g->queued || g->dirty)) { if (int rc = flush_group(g)) return rc; }
     if (int rc = ensure_buffers(g, p->width, p->height)) return rc;
     g->accumulating = accum;
+    {   // the set's traced rectangle: union over the frames submitted into it (every member computes the same one for its launch)
+        uint32_t rc4[4];
+        G_PT(g, 0, pt_traced_tile_rect(g->ctx[0], p, rc4));
+        uint32_t* u = g->rect[g->set];
+        if (g->queued == 0) { u[0] = rc4[0]; u[1] = rc4[1]; u[2] = rc4[2]; u[3] = rc4[3]; }
+        else if (rc4[2] > rc4[0] && rc4[3] > rc4[1]) {
+            if (u[2] <= u[0] || u[3] <= u[1]) { u[0] = rc4[0]; u[1] = rc4[1]; u[2] = rc4[2]; u[3] = rc4[3]; }
+            else { u[0] = rc4[0] < u[0] ? rc4[0] : u[0]; u[1] = rc4[1] < u[1] ? rc4[1] : u[1]; u[2] = rc4[2] > u[2] ? rc4[2] : u[2]; u[3] = rc4[3] > u[3] ? rc4[3] : u[3]; }
+        }
+        g->spp[g->set] = spp;
+    }
     // an accumulating sequence keeps its running sum on each member and re-delivers the running mean into slot 0 of the set
     const uint32_t j = accum ? 0u : g->queued;
     PtRenderParams q = *p;

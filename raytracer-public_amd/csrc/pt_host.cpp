@@ -295,7 +295,8 @@ void build_tri_records(const float* tris, uint32_t n, TriRecord* out) {
         const float cz = e1[0] * e2[1] - e1[1] * e2[0];
         const float inv = 1.0f / std::sqrt((cx * cx + cy * cy) + cz * cz);
         const float n[3] = {cx * inv, cy * inv, cz * inv};
-        for (int k = 0; k < 3; ++k) { r.axis[k][0] = p[k]; r.axis[k][1] = e1[k]; r.axis[k][2] = e2[k]; r.axis[k][3] = n[k]; }
+        for (int k = 0; k < 3; ++k) { r.axis[k][0] = p[k]; r.axis[k][1] = e1[k]; r.axis[k][2] = e2[k]; r.axis[k][3] = 0.0f; r.n[k] = n[k]; }
+        r.n[3] = 0.0f;
     }
 }
 
@@ -319,6 +320,18 @@ uint32_t tile_count_of(uint32_t width, uint32_t height, uint32_t rank, uint32_t 
     for (uint32_t ty = 0; ty < ty_n; ++ty) {
         const uint32_t first = (rank + count - ty % count) % count;
         if (first < tx_n) n += (tx_n - first + count - 1) / count;
+    }
+    return n;
+}
+
+// the rank's tiles inside the tile rectangle rect = {tx0, ty0, tx1, ty1} (packed tile shares, pt_kernels.hip)
+uint32_t rect_tile_count_of(uint32_t rank, uint32_t count, const uint32_t rect[4]) {
+    if (count == 0) count = 1;
+    if (rect[2] <= rect[0] || rect[3] <= rect[1]) return 0;
+    uint32_t n = 0;
+    for (uint32_t ty = rect[1]; ty < rect[3]; ++ty) {
+        const uint32_t first = rect[0] + (rank + count - ((ty + rect[0]) % count)) % count;
+        if (first < rect[2]) n += (rect[2] - first + count - 1) / count;
     }
     return n;
 }

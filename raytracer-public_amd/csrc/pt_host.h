@@ -37,13 +37,13 @@ struct WideNode {
 };
 static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 
-// Packed references: the traversal gathers triangle records (48 B) and wide nodes (64 B) from ONE arena, so a child reference
+// Packed references: the traversal gathers triangle records (64 B) and wide nodes (64 B) from ONE arena, so a child reference
 // is the record's position in it in 16-byte units -- `ref << 4` is the byte offset, and the shift drops the leaf flag:
-//   leaf        kLeafFlag | 3 * tri                 (triangle record `tri` at byte 48 * tri)
+//   leaf        kLeafFlag | 4 * tri                 (triangle record `tri` at byte 64 * tri)
 //   wide node   node_base16 + 4 * index             (node `index` at byte 16 * node_base16 + 64 * index)
 // A leaf whose triangle index is >= num_tris (the reference enters such a leaf and tests nothing, renderer.wgsl:262) points at
 // the all-zero record behind the last triangle (index num_tris: never hit, |det| < eps).
-inline uint32_t packed_leaf_ref(uint32_t tri, uint32_t num_tris) { return kLeafFlag | (3u * (tri < num_tris ? tri : num_tris)); }
+inline uint32_t packed_leaf_ref(uint32_t tri, uint32_t num_tris) { return kLeafFlag | (4u * (tri < num_tris ? tri : num_tris)); }
 struct WideBvh {
     std::vector<WideNode> nodes;
     uint32_t root_ref = kInvalid;      // same encoding as WideNode::ref; kInvalid = empty BVH
@@ -58,12 +58,14 @@ struct WideBvh {
 // no ray enters but which counts as an examined record, exactly as in the reference.
 bool build_wide_bvh(const uint32_t* bvh4, uint64_t words, uint32_t num_tris, uint32_t node_base16, WideBvh& out, std::string& err);
 
-// 48-byte triangle record: v0, e1 = v1-v0, e2 = v2-v0, n = normalize(cross(e1,e2)) -- the same
-// f32 operations renderer.wgsl:179-180,269 performs per visit, done once at upload.  Axis-major: piece a (16 bytes) holds
-// component a of the four vectors, (v0[a], e1[a], e2[a], n[a]) -- three lanes of a quad that fetch one piece each hold the
-// triangle in structure-of-arrays form for the quad's Moller-Trumbore (pt_megakernel.hip).
-struct TriRecord { float axis[3][4]; };
-static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
+// 64-byte triangle record (one cache line, like a wide node): v0, e1 = v1-v0, e2 = v2-v0, n = normalize(cross(e1,e2)) -- the same
+// f32 operations renderer.wgsl:179-180,269 performs per visit, done once at upload.  Pieces 0..2 are axis-major: piece a (16 bytes)
+// holds component a of the three vectors of the intersection test, (v0[a], e1[a], e2[a], 0) -- three lanes of a quad that fetch one
+// piece each hold the triangle in structure-of-arrays form for the quad's Moller-Trumbore (pt_megakernel.hip); piece 3 is the
+// normal (n, 0), which the shade pass fetches with ONE 16-byte request (as three components of three pieces it cost three, and the
+// vector L1's request rate is what the dense traversal is closest to: +2..3 % frame time, profiles/r04_q2_ab.txt).
+struct TriRecord { float axis[3][4]; float n[4]; };
+static_assert(sizeof(TriRecord) == 64, "TriRecord must be 64 bytes");
 void build_tri_records(const float* tris, uint32_t n, TriRecord* out);
 
 // ---- procedural stand-in scenes ---------------------------------------------------
@@ -74,5 +76,7 @@ constexpr uint32_t kTile = 8;   // 8x8-pixel tiles, one wavefront each
 void tile_list(uint32_t width, uint32_t height, uint32_t rank, uint32_t count, std::vector<uint32_t>& tiles);
 // tile_list(...).size() without building the list: per tile row, the rank's tiles are tx = first, first + count, ... with first = (rank - ty) mod count
 uint32_t tile_count_of(uint32_t width, uint32_t height, uint32_t rank, uint32_t count);
+// the rank's tiles inside the tile rectangle rect = {tx0, ty0, tx1, ty1} (half-open): what a packed share holds
+uint32_t rect_tile_count_of(uint32_t rank, uint32_t count, const uint32_t rect[4]);
 
 } // namespace pt

@@ -29,18 +29,13 @@
 #ifndef PT_QUAD_LIVE
 #define PT_QUAD_LIVE 16            // paths a wavefront may hold when it re-seats them (16 quads per wavefront)
 #endif
-#ifndef PT_CONSOLIDATE
-#define PT_CONSOLIDATE (PT_QUAD == 1 ? 0 : 1)           // drain consolidation: once the queue is dry the wavefronts of a SIMD hand their paths to one collector (pt_megakernel.hip)
-#endif
 #ifndef PT_FILL_THRESHOLD
 #define PT_FILL_THRESHOLD 4        // hand out ready camera rays when this many lanes of a wavefront are without a path (a fetch from the ray buffer is cheap: 4 beats 8 by 2 %)
 #endif
 
 namespace ptk {
 
-constexpr uint32_t kSimdKeys = 8192;     // hardware keys: xcc (3 bits) | se, sh, cu (8 bits) | simd (2 bits)
-constexpr uint32_t kSimdSlots = 1280;    // dense SIMD ids a launch can deal (MI355X: 1,024 SIMDs); a wavefront beyond that keeps its paths
-constexpr uint32_t kSimdCap = 512;       // records per SIMD ring (a power of two); 6 x 64 of them stay free for simultaneous reservations
+constexpr uint32_t kWaveTimeWords = 24;  // STATS diagnostics: 64-bit words per wavefront in RenderArgs::wave_times
 #define PT_MAX_BATCH 256    // frames per persistent launch (their per-frame parameters live in a small device array)
 // Per-frame part of the UBO for a batched launch (several consecutive frames traced by one persistent launch).
 struct FrameParams {
@@ -57,11 +52,11 @@ struct FrameChunk { FrameParams f[kFrameChunk]; float4* o[kFrameChunk]; };
 struct RenderArgs {
     // device scene, MI355X layouts
     const uint4*  nodes;        // WideNode[]: 64 B per internal BVH4 node, read as 4 x dwordx4
-    const float4* tris;         // TriRecord[]: 48 B per triangle, read as 3 x dwordx4
-    const uint4*  scene;        // the arena both arrays live in: triangle record t at byte 48 t, wide node i at byte node_off + 64 i;
+    const float4* tris;         // TriRecord[]: 64 B per triangle (three axis-major pieces + the normal)
+    const uint4*  scene;        // the arena both arrays live in: triangle record t at byte 64 t, wide node i at byte node_off + 64 i;
                                 // child references are positions in it in 16-byte units (packed references, pt_host.h)
     uint32_t      node_off;
-    uint32_t      tri_gate3;    // 3 * numTris when the UBO's numTris is smaller than the uploaded triangle count (leaves past it are entered, not tested), else 0xFFFFFFFF
+    uint32_t      tri_gate;     // 4 * numTris (16-byte units) when the UBO's numTris is smaller than the uploaded triangle count (leaves past it are entered, not tested), else 0xFFFFFFFF
     // device scene, reference layouts (literal packet kernel, LBVH build, readback)
     const uint32_t* bvh4_ref;   // u32[1 + 8*M]   renderer.wgsl:91-111
     const float*    tris9;      // f32[9*N]       renderer.wgsl:82-89
@@ -88,7 +83,7 @@ struct RenderArgs {
     uint32_t* queue;            // global item cursor
     uint2*    spill;            // deep stack entries: [entry][grid lane]
     uint4*    raybuf;           // per wavefront of the grid: 64 camera-ray records of 3 x uint4 (o, d, inv, key, sample index), generated 64 at a time
-    unsigned long long* wave_times;   // STATS diagnostics: 8 words per wave (begin, queue-empty, end ticks @100 MHz, loop counts)
+    unsigned long long* wave_times;   // STATS diagnostics: kWaveTimeWords words per wave (begin, queue-empty, end ticks @100 MHz, loop counts, ...)
     // Queue enumeration vs sample storage.  The queue hands out (frame, traced tile, sample) batches of 64 pixel-samples;
     // `trace_slots` lists the owned-tile slots that are traced at all (nullptr = every owned tile): tiles whose every camera ray
     // provably misses the root box are left out (pt_api.cpp: screen rectangle of the root box) and keep the primed miss value.
@@ -102,15 +97,8 @@ struct RenderArgs {
     uint32_t  xcd_span;                   // 0: one queue; else items per XCD range (8 cursors at queue[8..15])
     uint32_t  num_batches, perm_cols;     // real (frame, traced tile, sample) batches of the queue; columns of the batch transpose
     uint32_t  perm_rows, perm_rows_magic; // its rows and floor(2^32 / rows) for the division
-    // drain consolidation (pt_megakernel.hip): per SIMD one 64-bit state word (bits 0..7 registered wavefronts, bit 8 collector present,
-    // bits 32..63 records reserved), the collector's published read position, a ring of simd_cap 64 B path records (o, d, T, rad, key, item,
-    // bounce) with one flag each (= simd_epoch + absolute index + 1 once the record is complete); simd_ids: hardware key -> dense SIMD id + 1
-    // (dealt on first use; [kSimdKeys] is the id counter)
-    unsigned long long* simd_state; uint32_t* simd_head; uint32_t* simd_ids;
-    float4*   simd_pool; uint32_t* simd_flags;
-    uint32_t  simd_slots, simd_cap, simd_epoch, consolidate;
     uint32_t  shade_threshold, fill_threshold;
-    uint32_t  quad_live;        // re-seat the paths one per quad once the wavefront has nothing left to start and holds at most this many (0: never; needs consolidate == 0)
+    uint32_t  quad_live;        // re-seat the paths one per quad once the wavefront has nothing left to start and holds at most this many (0: never)
     // batched launch: frames[i] / outs[i] for i < num_frames; items of frame i are batches [i*batches_per_frame, ...)
     const FrameParams* frames; float4* const* outs;     // device arrays of the frame slot, filled by launch_frame_params
     uint32_t  num_frames, batches_per_frame;
@@ -153,6 +141,11 @@ hipError_t launch_wide_nodes(const BuildBuffers& B, const uint32_t* bvh4, uint32
 // gathered: rank r's share of frame j at gathered + r * rank_stride_px + j * frame_stride_px; frame j goes to full + j * full_stride_px
 hipError_t launch_deinterleave(const float4* gathered, uint64_t rank_stride_px, uint64_t frame_stride_px, uint32_t frames, float4* full, uint64_t full_stride_px,
                                uint32_t width, uint32_t height, uint32_t count, hipStream_t stream);
+// packed tile shares (pt_kernels.hip): rank's tiles inside the tile rectangle rect = {tx0, ty0, tx1, ty1}, 64 x 3 floats each
+hipError_t launch_pack_shares(const float4* compact, uint64_t frame_stride_px, uint32_t frames, float* packed, uint64_t packed_stride_floats, uint32_t width,
+                              uint32_t rank, uint32_t count, const uint32_t rect[4], hipStream_t stream);
+hipError_t launch_unpack_frames(const float* gathered, uint64_t rank_stride_floats, uint64_t frame_stride_floats, uint32_t frames, float4* full, uint64_t full_stride_px,
+                                uint32_t width, uint32_t height, uint32_t count, const uint32_t rect[4], uint32_t spp, hipStream_t stream);
 hipError_t launch_rgba8(const float4* src, uint32_t* dst, uint32_t n, hipStream_t stream);
 hipError_t launch_tonemap(const float4* src, uint32_t* dst, uint32_t width, uint32_t height, int from_rgba8, hipStream_t stream);
 

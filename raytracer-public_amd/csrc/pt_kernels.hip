@@ -37,9 +37,9 @@ __device__ __forceinline__ bool traverse(const RenderArgs& A, const Ray& r, floa
     for (;;) {
         bool need_pop = false;
         if (cur & kLeaf) {
-            const uint32_t ti3 = cur & 0x7fffffffu;               // packed reference: 3 * triangle index (16-byte units of 48 B records)
-            if (ti3 < 3u * A.num_tris) {                          // renderer.wgsl:262 (an out-of-range leaf points at record num_tris)
-                const uint32_t ti = __umulhi(ti3, 0xAAAAAAABu) >> 1;
+            const uint32_t ti4 = cur & 0x7fffffffu;               // packed reference: 4 * triangle index (16-byte units of 64 B records)
+            if (ti4 < 4u * A.num_tris) {                          // renderer.wgsl:262 (an out-of-range leaf points at record num_tris)
+                const uint32_t ti = ti4 >> 2;
                 const float4* tp = (const float4*)arena_record(A, cur);
                 const float4 a = tp[0], b = tp[1], c = tp[2];
                 if (STATS) cnt.tris += 1;
@@ -116,7 +116,7 @@ template <bool ANYHIT, bool STATS>
 __device__ __forceinline__ bool brute_trace(const RenderArgs& A, const Ray& r, float& best_t, uint32_t& best_prim, Counters& cnt) {
     best_t = kInfT; best_prim = kInvalidRef;
     for (uint32_t ti = 0; ti < A.num_tris; ++ti) {
-        const float4* tp = A.tris + (size_t)ti * 3;
+        const float4* tp = A.tris + (size_t)ti * 4;
         const float4 a = tp[0], b = tp[1], c = tp[2];
         if (STATS) cnt.tris += 1;
         const F3 v0 = f3(a.x, b.x, c.x), e1 = f3(a.y, b.y, c.y), e2 = f3(a.z, b.z, c.z);     // axis-major record (pt_host.h::TriRecord)
@@ -301,10 +301,24 @@ template <bool STATS>
 __global__ __launch_bounds__(256) void render_packet_kernel(const RenderArgs A) {
     __shared__ uint2 pstack[kStackMax][64];                  // [entry][packet of the block]: (node index, lane mask)
     const uint32_t lane = threadIdx.x & 63u, sub = threadIdx.x & 3u;
-    const uint32_t pk = threadIdx.x >> 2;                    // packet of the block: 8 x 8 packets = 16 x 16 pixels
-    const uint32_t gx = blockIdx.x * 8u + (pk & 7u), gy = blockIdx.y * 8u + (pk >> 3);
-    const uint32_t px = gx * 2u + (sub & 1u), py = gy * 2u + (sub >> 1);
-    const bool in_image = px < A.width && py < A.height;     // renderer.wgsl:376-385: lanes outside the image stay inactive
+    const uint32_t pk = threadIdx.x >> 2;                    // packet of the block
+    uint32_t px, py; size_t out_index; bool owned = true;
+    if (A.compact != 0u) {
+        // a tile share (pixel-tile sharding): an 8 x 8 tile is 4 x 4 whole packets (packets start at even pixels,
+        // renderer.wgsl:359), so every packet of the image belongs to exactly one rank; a block takes four owned tiles, the output is
+        // the compact tile-major buffer
+        const uint32_t slot = blockIdx.x * 4u + (pk >> 4), pin = pk & 15u;
+        owned = slot < A.num_tiles;
+        const uint32_t tile = owned ? (A.tiles ? A.tiles[slot] : slot) : 0u;
+        const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+        px = tx * 8u + (pin & 3u) * 2u + (sub & 1u); py = ty * 8u + (pin >> 2) * 2u + (sub >> 1);
+        out_index = (size_t)slot * 64u + (py & 7u) * 8u + (px & 7u);
+    } else {
+        const uint32_t gx = blockIdx.x * 8u + (pk & 7u), gy = blockIdx.y * 8u + (pk >> 3);       // 8 x 8 packets = 16 x 16 pixels
+        px = gx * 2u + (sub & 1u); py = gy * 2u + (sub >> 1);
+        out_index = (size_t)py * A.width + px;
+    }
+    const bool in_image = owned && px < A.width && py < A.height;     // renderer.wgsl:376-385: lanes outside the image stay inactive
     Ray r;
     if (in_image) r = primary_ray(A, (float)px + 0.5f, (float)py + 0.5f);
     else { r.o = f3(0, 0, 0); r.d = f3(0, 0, -1.0f); r.inv = f3(kInfT, kInfT, kInfT); }
@@ -408,9 +422,8 @@ __global__ __launch_bounds__(256) void render_packet_kernel(const RenderArgs A) 
         const F3 L = light_dir();
         F3 col = f3(0.01f, 0.01f, 0.01f);
         if (btri != kInvalidRef) col = base * (0.15f + wmax(dot3(bn, L), 0.0f));
-        const size_t o = (size_t)py * A.width + px;
-        A.out[o] = make_float4(col.x, col.y, col.z, 1.0f);
-        if (A.tri_ids) A.tri_ids[o] = btri;
+        A.out[out_index] = make_float4(col.x, col.y, col.z, 1.0f);
+        if (A.tri_ids) A.tri_ids[out_index] = btri;
     }
     if (STATS) {
         if (in_image) { atomicAdd(&A.stats[0], 1ull); atomicAdd(&A.stats[6], 1ull); }      // one closest ray / sample per pixel of the image
@@ -551,6 +564,66 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const float4* __restr
     full[(size_t)blockIdx.y * full_stride_px + (size_t)py * width + px] = gathered[(size_t)rank * stride_px + (size_t)blockIdx.y * frame_stride_px + (size_t)slot * 64 + lane];
 }
 
+// ---- packed tile shares: what a sharded frame ships to rank 0 ---------------------------------------------------------------------
+// A rank's compact buffer holds every owned tile at 16 bytes per pixel.  Two thirds of a dragon-class frame's tiles lie outside the
+// rectangle of tiles in which a camera ray can reach the scene at all (pt_traced_tile_rect): their pixels are the camera-miss value, a
+// constant; and alpha is 1 everywhere.  So only the owned tiles INSIDE the rectangle travel, as 12 bytes per pixel: rank r's share of a
+// frame is its tiles inside the rectangle in row-major order, 64 x 3 floats each.  Tile (tx, ty) belongs to rank (tx + ty) % count.
+struct TileRectArg { uint32_t tx0, ty0, tx1, ty1; };
+// slot of tile (tx, ty) among its rank's tiles of the half-open tile range [x0, x1) x [y0, ..): over `count` consecutive rows a rank's first
+// column takes every residue once, so such a block of rows holds (x1 - x0) of its tiles
+__device__ __forceinline__ uint32_t share_slot(uint32_t tx, uint32_t ty, uint32_t rank, uint32_t count, uint32_t x0, uint32_t x1, uint32_t y0) {
+    const uint32_t rows = ty - y0;
+    uint32_t slot = (rows / count) * (x1 - x0);
+    auto first_col = [&](uint32_t row) { return x0 + (rank + count - ((row + x0) % count)) % count; };       // the rank's first tile column >= x0 in that row
+    for (uint32_t r = ty - rows % count; r < ty; ++r) {
+        const uint32_t f = first_col(r);
+        slot += f < x1 ? (x1 - f + count - 1u) / count : 0u;
+    }
+    return slot + (tx - first_col(ty)) / count;
+}
+
+// blockIdx.y = frame; one wavefront per tile of the rectangle, the tiles of other ranks are skipped
+__global__ __launch_bounds__(256) void pack_shares_kernel(const float4* __restrict__ compact, uint64_t frame_stride_px, float* __restrict__ packed, uint64_t packed_stride_floats,
+                                                          uint32_t tiles_x, uint32_t rank, uint32_t count, TileRectArg rc) {
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = item >> 6, lane = item & 63u;
+    const uint32_t rw = rc.tx1 - rc.tx0;
+    if (t >= rw * (rc.ty1 - rc.ty0)) return;
+    const uint32_t tx = rc.tx0 + t % rw, ty = rc.ty0 + t / rw;
+    if ((tx + ty) % count != rank) return;
+    const uint32_t owned = share_slot(tx, ty, rank, count, 0u, tiles_x, 0u), inside = share_slot(tx, ty, rank, count, rc.tx0, rc.tx1, rc.ty0);
+    const float4 v = compact[(size_t)blockIdx.y * frame_stride_px + (size_t)owned * 64u + lane];
+    float* o = packed + (size_t)blockIdx.y * packed_stride_floats + ((size_t)inside * 64u + lane) * 3u;
+    o[0] = v.x; o[1] = v.y; o[2] = v.z;
+}
+
+// rank 0: blockIdx.y = frame; every pixel of the row-major frame from the gathered packed shares, or -- outside the rectangle -- the
+// camera-miss mean: `spp` additions of the miss value and the multiplication by 1 / spp, as resolve_kernel forms it (the same bits)
+__global__ __launch_bounds__(256) void unpack_frames_kernel(const float* __restrict__ gathered, uint64_t rank_stride_floats, uint64_t frame_stride_floats, float4* __restrict__ full,
+                                                            uint64_t full_stride_px, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t tiles_y, uint32_t count,
+                                                            TileRectArg rc, uint32_t spp) {
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tile = item >> 6, lane = item & 63u;
+    if (tile >= tiles_x * tiles_y) return;
+    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
+    if (px >= width || py >= height) return;
+    float4 v;
+    if (tx >= rc.tx0 && tx < rc.tx1 && ty >= rc.ty0 && ty < rc.ty1) {
+        const uint32_t rank = (tx + ty) % count;
+        const float* src = gathered + (size_t)rank * rank_stride_floats + (size_t)blockIdx.y * frame_stride_floats + ((size_t)share_slot(tx, ty, rank, count, rc.tx0, rc.tx1, rc.ty0) * 64u + lane) * 3u;
+        v = make_float4(src[0], src[1], src[2], 1.0f);
+    } else {
+        const float bg = 0.0f + 1.0f * kBgPrimary;
+        float sum = 0.0f;
+        for (uint32_t s = 0; s < spp; ++s) sum = sum + bg;
+        const float m = sum * (1.0f / (float)spp);
+        v = make_float4(m, m, m, 1.0f);
+    }
+    full[(size_t)blockIdx.y * full_stride_px + (size_t)py * width + px] = v;
+}
+
 __global__ __launch_bounds__(256) void rgba8_kernel(const float4* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -611,7 +684,9 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__
 // ------------------------------------------------------------------------------------
 hipError_t launch_render(const RenderArgs& A, int kmode, bool stats, hipStream_t stream) {
     if (kmode == PT_KMODE_PACKET) {
-        const dim3 grid((A.width + 15) / 16, (A.height + 15) / 16);   // 256 lanes = 64 packets of 2 x 2 pixels = 16 x 16 pixels
+        // 256 lanes = 64 packets of 2 x 2 pixels: 16 x 16 pixels of a whole frame, four owned 8 x 8 tiles of a tile share
+        const dim3 grid = A.compact ? dim3((A.num_tiles + 3u) / 4u, 1) : dim3((A.width + 15) / 16, (A.height + 15) / 16);
+        if (grid.x == 0) return hipSuccess;
         if (stats) hipLaunchKernelGGL(render_packet_kernel<true>, grid, dim3(256), 0, stream, A);
         else       hipLaunchKernelGGL(render_packet_kernel<false>, grid, dim3(256), 0, stream, A);
         return hipGetLastError();
@@ -657,6 +732,25 @@ hipError_t launch_deinterleave(const float4* gathered, uint64_t rank_stride_px, 
     const uint32_t items = tx * ty * 64u;
     if (frames == 0u) return hipSuccess;
     hipLaunchKernelGGL(deinterleave_kernel, dim3((items + 255) / 256, frames), dim3(256), 0, stream, gathered, rank_stride_px, frame_stride_px, full, full_stride_px, width, height, tx, ty, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_shares(const float4* compact, uint64_t frame_stride_px, uint32_t frames, float* packed, uint64_t packed_stride_floats, uint32_t width,
+                              uint32_t rank, uint32_t count, const uint32_t rect[4], hipStream_t stream) {
+    const TileRectArg rc = {rect[0], rect[1], rect[2], rect[3]};
+    const uint32_t items = (rc.tx1 - rc.tx0) * (rc.ty1 - rc.ty0) * 64u;
+    if (frames == 0u || items == 0u) return hipSuccess;
+    hipLaunchKernelGGL(pack_shares_kernel, dim3((items + 255) / 256, frames), dim3(256), 0, stream, compact, frame_stride_px, packed, packed_stride_floats, (width + 7) / 8, rank, count, rc);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_frames(const float* gathered, uint64_t rank_stride_floats, uint64_t frame_stride_floats, uint32_t frames, float4* full, uint64_t full_stride_px,
+                                uint32_t width, uint32_t height, uint32_t count, const uint32_t rect[4], uint32_t spp, hipStream_t stream) {
+    const uint32_t tx = (width + 7) / 8, ty = (height + 7) / 8;
+    const TileRectArg rc = {rect[0], rect[1], rect[2], rect[3]};
+    if (frames == 0u) return hipSuccess;
+    hipLaunchKernelGGL(unpack_frames_kernel, dim3((tx * ty * 64u + 255) / 256, frames), dim3(256), 0, stream, gathered, rank_stride_floats, frame_stride_floats, full, full_stride_px,
+                       width, height, tx, ty, count, rc, spp);
     return hipGetLastError();
 }
 

@@ -125,6 +125,11 @@ class PathTracer {
     const w = this.canvas.width, h = this.canvas.height, q = fromRGBA8 !== false;
     return this.group ? native().groupReadTonemapped(this.group, w, h, q) : native().readTonemapped(this.device, w, h, q);
   }
+  // Checkpoint / resume of a progressive accumulation (options.accumulate): the raw running sums (f32 RGB sums + sample count per pixel).
+  // readAccumulation() -> { width, height, tileRank, tileCount, compact, samples, data: Float32Array }; restoreAccumulation(that object) on a
+  // PathTracer with the same scene continues bit for bit with the next render() (frame counts go on where the dumped run stopped).
+  readAccumulation() { if (this.group) throw new Error("readAccumulation: per-context state; on a group use the member contexts"); return native().readAccumulation(this.device); }
+  restoreAccumulation(dump) { if (this.group) throw new Error("restoreAccumulation: per-context state; on a group use the member contexts"); native().restoreAccumulation(this.device, dump); }
   lastRenderMs() { if (this.group) throw new Error("lastRenderMs: per-context timing; not available on a group"); return native().lastRenderMs(this.device); }
   getStats() { if (this.group) throw new Error("getStats: per-context counters; not available on a group"); return native().getStats(this.device); }
   synchronize() { if (this.group) native().groupSynchronize(this.group); else native().synchronize(this.device); }

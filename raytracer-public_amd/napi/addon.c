@@ -353,6 +353,34 @@ static napi_value read_u8(napi_env env, napi_callback_info info, int which) {
     else { bool q = true; napi_get_value_bool(env, argv[3], &q); PT_CALL(ctx, pt_read_tonemapped(ctx, q ? 1 : 0, (uint8_t*)out, n), "pt_read_tonemapped"); }
     return ta;
 }
+/* checkpoint of a progressive accumulation (pt_read_accum): { width, height, tileRank, tileCount, compact, samples, data: Float32Array } */
+static napi_value fn_read_accum(napi_env env, napi_callback_info info) {
+    napi_value argv[1]; if (!get_args(env, info, 1, argv)) return NULL;
+    PtContext* ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    PtAccumInfo ai; PT_CALL(ctx, pt_accum_info(ctx, &ai), "pt_accum_info");
+    if (ai.floats == 0) { napi_throw_error(env, "PT4", "readAccumulation: no running accumulation (render with accumulate first)"); return NULL; }
+    void* out; napi_value ta = make_typed(env, napi_float32_array, 4, (size_t)ai.floats, &out); if (!ta) return NULL;
+    PT_CALL(ctx, pt_read_accum(ctx, (float*)out, ai.floats), "pt_read_accum");
+    napi_value o; NAPI_OK(napi_create_object(env, &o));
+    set_num(env, o, "width", ai.width); set_num(env, o, "height", ai.height); set_num(env, o, "tileRank", ai.tile_rank); set_num(env, o, "tileCount", ai.tile_count);
+    set_num(env, o, "compact", ai.compact); set_num(env, o, "samples", ai.samples);
+    napi_set_named_property(env, o, "data", ta);
+    return o;
+}
+static napi_value fn_set_accum(napi_env env, napi_callback_info info) {          /* (ctx, the object readAccumulation returned) */
+    napi_value argv[2]; if (!get_args(env, info, 2, argv)) return NULL;
+    PtContext* ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    PtAccumInfo ai; memset(&ai, 0, sizeof ai);
+    ai.width = prop_u32(env, argv[1], "width", 0); ai.height = prop_u32(env, argv[1], "height", 0); ai.tile_rank = prop_u32(env, argv[1], "tileRank", 0);
+    ai.tile_count = prop_u32(env, argv[1], "tileCount", 1); ai.compact = prop_u32(env, argv[1], "compact", 0); ai.samples = prop_u32(env, argv[1], "samples", 0);
+    napi_value dv; bool has = false;
+    if (napi_has_named_property(env, argv[1], "data", &has) != napi_ok || !has) { napi_throw_type_error(env, NULL, "restoreAccumulation: no `data`"); return NULL; }
+    napi_get_named_property(env, argv[1], "data", &dv);
+    void* d; size_t len; if (!get_typed(env, dv, napi_float32_array, &d, &len)) return NULL;
+    ai.floats = len;
+    PT_CALL(ctx, pt_set_accum(ctx, &ai, (const float*)d), "pt_set_accum");
+    return NULL;
+}
 static napi_value fn_read_rgba8(napi_env env, napi_callback_info info) { return read_u8(env, info, 1); }       /* outputTex, PathTracer.js:163-172 */
 static napi_value fn_read_tonemapped(napi_env env, napi_callback_info info) { return read_u8(env, info, 2); }  /* tonemapper.wgsl */
 
@@ -493,6 +521,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"setBVH4", fn_set_bvh4}, {"setBVH2", fn_set_bvh2}, {"setSpheres", fn_set_spheres}, {"sceneInfo", fn_scene_info},
         {"render", fn_render}, {"setBatch", fn_set_batch}, {"flush", fn_flush}, {"lastRenderMs", fn_last_ms}, {"synchronize", fn_sync}, {"getStats", fn_stats},
         {"readRadiance", fn_read_radiance}, {"readRGBA8", fn_read_rgba8}, {"readTonemapped", fn_read_tonemapped},
+        {"readAccumulation", fn_read_accum}, {"restoreAccumulation", fn_set_accum},
         {"groupCreate", fn_group_create}, {"groupDestroy", fn_group_destroy}, {"groupSize", fn_group_size},
         {"groupSetTriangles", fn_group_set_triangles}, {"groupBuildBVH", fn_group_build_bvh}, {"groupSetBVH4", fn_group_set_bvh4}, {"groupSetBVH2", fn_group_set_bvh2},
         {"groupReadBVH2", fn_group_read_bvh2}, {"groupSetBatch", fn_group_set_batch}, {"groupRender", fn_group_render}, {"groupFlush", fn_group_flush},

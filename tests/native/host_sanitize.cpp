@@ -53,16 +53,16 @@ static void one_case(uint32_t n, uint32_t seed, int flavour) {
         orc_bvh4_wide(bvh2.data(), ow.data());
         CHECK(w == ow, "bvh4_wide product == oracle");
         pt::WideBvh wb;
-        CHECK(pt::build_wide_bvh(b4.data(), b4.size(), n, 3u * n + 7u, wb, err), "device layout from collapse");
-        CHECK(pt::build_wide_bvh(w.data(), w.size(), n, 3u * n + 7u, wb, err), "device layout from bvh4_wide");
+        CHECK(pt::build_wide_bvh(b4.data(), b4.size(), n, 4u * n + 4u, wb, err), "device layout from collapse");
+        CHECK(pt::build_wide_bvh(w.data(), w.size(), n, 4u * n + 4u, wb, err), "device layout from bvh4_wide");
     }
     std::vector<pt::TriRecord> rec(n);
     pt::build_tri_records(tris.data(), n, rec.data());
     // malformed buffers must be rejected, not read out of bounds
     if (n >= 2) {
         std::vector<uint32_t> bad = b4; bad[1 + 3] = 0;                       // root's first child = root: cycle
-        pt::WideBvh wb; CHECK(!pt::build_wide_bvh(bad.data(), bad.size(), n, 3u * n + 7u, wb, err), "cycle rejected");
-        bad = b4; CHECK(!pt::build_wide_bvh(bad.data(), bad.size() - 9, n, 3u * n + 7u, wb, err), "short buffer rejected");
+        pt::WideBvh wb; CHECK(!pt::build_wide_bvh(bad.data(), bad.size(), n, 4u * n + 4u, wb, err), "cycle rejected");
+        bad = b4; CHECK(!pt::build_wide_bvh(bad.data(), bad.size() - 9, n, 4u * n + 4u, wb, err), "short buffer rejected");
         std::vector<uint32_t> bad2 = bvh2; bad2[1 + 3] = 0x7fffffffu;
         std::vector<uint32_t> out; CHECK(!pt::collapse_to_bvh4(bad2.data(), n, out, err), "out-of-range child rejected");
     }

@@ -230,6 +230,10 @@ def test_bench_single_gpu_contract_line():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_busy_ms", "algorithmic"):
         assert k in rf, k
     assert rf["frames_per_launch"] == 12.0 and rf["launches"] == 1
+    # the timed region is repeated; the line carries the median repetition and the spread
+    assert r["reps"] == 3 and len(r["ms_per_step_all"]) == 3 and r["ms_per_step_min_max"][0] <= r["ms_per_step"] <= r["ms_per_step_min_max"][1]
+    assert sorted(r["ms_per_step_all"])[1] == r["ms_per_step"]
+    assert set(rf["peak_source"]) == {"l1_gather_requests", "valu_issue", "l2_bandwidth", "hbm_fabric"}
     # the trace kernel is busy for most of the timed region and never longer than it
     assert 0.3 * r["ms_per_step"] * 12 < rf["kernel_busy_ms"] <= r["ms_per_step"] * 12 * 1.02
     assert rf["frac"] is None or 0.0 < rf["frac"] <= 1.0
@@ -301,7 +305,8 @@ def test_buffer_busy_tracks_queued_and_delivered_frames(rt, gpu_ctx):
         gpu_ctx.set_output_buffer(bufs[0], w * h * 4); gpu_ctx.render(p)
         gpu_ctx.set_output_buffer(bufs[1], w * h * 4); p.frame = 1; gpu_ctx.render(p)
         assert gpu_ctx.buffer_busy(bufs[0], nbytes) and gpu_ctx.buffer_busy(bufs[1], nbytes)      # queued, not launched yet
-        assert not gpu_ctx.buffer_busy(bufs[0] + 16, nbytes - 16)                                # a range no frame starts in
+        assert gpu_ctx.buffer_busy(bufs[0] + 16, 16) and gpu_ctx.buffer_busy(bufs[0] + nbytes - 4, 64)    # any overlap with a frame's bytes counts
+        assert not gpu_ctx.buffer_busy(bufs[0] + nbytes, 64) or bufs[1] == bufs[0] + nbytes        # just behind the frame: free
         gpu_ctx.set_output_buffer(0, 0)                                                         # launches the partial batch and waits
         assert not gpu_ctx.buffer_busy(bufs[0], nbytes) and not gpu_ctx.buffer_busy(bufs[1], nbytes)
         out = np.zeros((h, w, 4), np.float32)
@@ -309,6 +314,33 @@ def test_buffer_busy_tracks_queued_and_delivered_frames(rt, gpu_ctx):
         gpu_ctx.set_batch(1)
         gpu_ctx.render(p)
         assert same_bits(out, gpu_ctx.read_radiance())
+        # More launches in flight than there are frame slots: the first launch targets bufs[0], two dozen heavier ones
+        # into bufs[1] follow without a host wait; bufs[0] must read busy until ITS launch has delivered, whatever slot is reused meanwhile,
+        # and free afterwards without anybody having waited for the later ones explicitly.
+        tris2 = rt.procedural_scene(0, 20000)
+        gpu_ctx.set_triangles(tris2); gpu_ctx.build_bvh()
+        big_w, big_h = 512, 288
+        big = []
+        for _ in range(2):
+            ptr = C.c_void_p()
+            assert hip.hipMalloc(C.byref(ptr), C.c_size_t(big_w * big_h * 16)) == 0
+            big.append(ptr.value)
+        bufs.extend(big)
+        q = gpu_ctx.make_params(big_w, big_h, mode=rt.PT_MODE_PATH, spp=8, max_bounces=8)
+        gpu_ctx.synchronize()
+        gpu_ctx.set_output_buffer(big[0], big_w * big_h * 4); gpu_ctx.render(q)
+        gpu_ctx.set_output_buffer(big[1], big_w * big_h * 4)
+        seen_busy_first = gpu_ctx.buffer_busy(big[0], 16)
+        for i in range(24):
+            q.frame = i + 1; gpu_ctx.render(q)
+        assert gpu_ctx.buffer_busy(big[1], big_w * big_h * 16)                                     # 24 launches queued behind each other
+        assert seen_busy_first                                                                       # the launch had just been submitted
+        r = gpu_ctx.make_params(big_w, big_h, mode=rt.PT_MODE_PATH, spp=8, max_bounces=8, simple_kernel=True)       # the one-pixel-per-lane kernel is tracked as well
+        gpu_ctx.set_output_buffer(big[0], big_w * big_h * 4); gpu_ctx.render(r)
+        assert gpu_ctx.buffer_busy(big[0] + 1024, 4)
+        gpu_ctx.synchronize()
+        assert not gpu_ctx.buffer_busy(big[0], big_w * big_h * 16) and not gpu_ctx.buffer_busy(big[1], big_w * big_h * 16)
+        gpu_ctx.set_output_buffer(0, 0)
     finally:
         for b in bufs:
             hip.hipFree(C.c_void_p(b))
@@ -349,3 +381,57 @@ def test_deinterleave_batch_scatters_every_frame_of_a_gathered_batch(rt, gpu_ctx
             gpu_ctx.deinterleave_batch(g_ptr.value, stride, stride, frames, w, h, world, f_ptr.value, w * h * 4)     # rank stride too small for three frames
     finally:
         hip.hipFree(g_ptr); hip.hipFree(f_ptr)
+
+
+@pytest.mark.parametrize("w,h,world,cam,spp", [(200, 120, 3, (0, 0, 2.5), 2), (97, 61, 4, (0.2, -0.1, 4.0), 3), (160, 96, 2, (0, 0, 0.2), 1), (96, 64, 8, (30.0, 0, 2.5), 2)])
+def test_packed_shares_rebuild_every_frame(rt, gpu_ctx, w, h, world, cam, spp):
+    """pt_traced_tile_rect / pt_pack_shares / pt_unpack_batch: each rank's frames packed (its tiles inside the traced rectangle, 12 bytes per
+    pixel), laid out as one gather would leave them on the root, rebuilt by ONE launch -- every frame equals the whole-frame render bit for
+    bit: a rectangle inside the image, the whole image (camera inside the scene), an EMPTY rectangle (scene off-screen: nothing travels),
+    odd sizes, 2 / 3 / 4 / 8 ranks; the rectangle is the one the launches trace; pt_packed_tile_ids is the buffer's order."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    tris = (random_soup(500, 7).reshape(-1, 3) * np.float32(0.6)).astype(np.float32).reshape(-1)
+    gpu_ctx.set_triangles(tris); gpu_ctx.build_bvh()
+    frames = 3
+    kw = dict(mode=rt.PT_MODE_PATH, spp=spp, max_bounces=3, seed=3)
+    rect = gpu_ctx.traced_tile_rect(gpu_ctx.make_params(w, h, cam, **kw))
+    tiles_x, tiles_y = (w + 7) // 8, (h + 7) // 8
+    assert 0 <= rect[0] <= rect[2] <= tiles_x and 0 <= rect[1] <= rect[3] <= tiles_y
+    if cam[2] < 1.0: assert rect == (0, 0, tiles_x, tiles_y)                 # camera inside the root box: nothing can be left out
+    if cam[0] > 10.0: assert (rect[2] - rect[0]) * (rect[3] - rect[1]) == 0  # scene far off-screen: nothing to trace, nothing to ship
+    stride = max(rt.tile_layout(w, h, r, world)[1] for r in range(world))
+    max_tiles, pstride = rt.packed_layout(w, h, world, rect)
+    assert pstride == max_tiles * 192 and pstride <= stride * 3 // 4
+    for r in range(world):
+        ids = rt.packed_tile_ids(w, h, r, world, rect).tolist()
+        assert ids == [t for t in rt.tile_ids(w, h, r, world).tolist() if rect[0] <= t % tiles_x < rect[2] and rect[1] <= t // tiles_x < rect[3]] and len(ids) <= max_tiles
+    c_ptr, p_ptr, f_ptr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(c_ptr), C.c_size_t(frames * stride * 4)) == 0
+    assert hip.hipMalloc(C.byref(p_ptr), C.c_size_t(max(world * frames * pstride * 4, 64))) == 0
+    assert hip.hipMalloc(C.byref(f_ptr), C.c_size_t(frames * w * h * 16)) == 0
+    try:
+        for r in range(world):
+            for j in range(frames):
+                gpu_ctx.set_compact_buffer(c_ptr.value + j * stride * 4, stride)
+                gpu_ctx.render(gpu_ctx.make_params(w, h, cam, frame=j, tile_rank=r, tile_count=world, **kw))
+            if pstride:        # rank r's packed frames where a gather would put them: [rank][frame][pstride]
+                gpu_ctx.pack_shares(c_ptr.value, stride, frames, w, h, r, world, rect, p_ptr.value + r * frames * pstride * 4, pstride)
+            gpu_ctx.synchronize()
+        gpu_ctx.unpack_batch(p_ptr.value, frames * pstride, pstride, frames, w, h, world, rect, spp, f_ptr.value, w * h * 4)
+        last = gpu_ctx.read_radiance(w, h).copy()
+        got = np.zeros((frames, h, w, 4), np.float32)
+        gpu_ctx.synchronize()
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), f_ptr, C.c_size_t(got.nbytes), C.c_int(2)) == 0
+        gpu_ctx.set_compact_buffer(0, 0)
+        for j in range(frames):
+            gpu_ctx.render(gpu_ctx.make_params(w, h, cam, frame=j, **kw))
+            assert same_bits(got[j], gpu_ctx.read_radiance()), j
+        assert same_bits(last, got[frames - 1])
+        gpu_ctx.unpack_batch(p_ptr.value, frames * pstride, pstride, frames, w, h, world, rect, spp)          # own frame buffer: the last frame
+        assert same_bits(gpu_ctx.read_radiance(w, h), got[frames - 1])
+        with pytest.raises(rt.PtError):
+            gpu_ctx.unpack_batch(p_ptr.value, frames * pstride, pstride, frames, w, h, world, (0, 0, tiles_x + 1, tiles_y), spp)     # rectangle outside the image
+    finally:
+        hip.hipFree(c_ptr); hip.hipFree(p_ptr); hip.hipFree(f_ptr)
+

@@ -59,6 +59,58 @@ def test_group_of_members_on_one_gpu_equals_the_whole_frame(rt, orc, scene, memb
         g.close()
 
 
+def test_group_result_survives_a_change_of_batch_and_shape(rt, scene):
+    """The last gathered frame lives in rank 0's own frame buffer, not in the group's batch buffers: pt_group_set_batch (which frees and
+    re-sizes those) and a read-back afterwards deliver the frame that was rendered (it used to be read from freed memory)."""
+    g = rt.Group([0, 0, 0], rt.PT_GROUP_TRANSPORT_COPY)
+    one = rt.Context(0)
+    try:
+        g.set_triangles(scene); g.build_bvh()
+        one.set_triangles(scene); one.build_bvh()
+        kw = dict(mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=4)
+        g.set_batch(3)
+        for f in range(3):
+            g.render(g.make_params(176, 104, frame=f, **kw))
+        g.set_batch(1)                                           # frees the batch-sized gather buffers
+        scratch = [rt.Context(0) for _ in range(2)]              # something else allocates and writes meanwhile
+        for c in scratch:
+            c.set_triangles(scene); c.build_bvh(); c.render(c.make_params(640, 360, **kw)); c.read_radiance(); c.close()
+        one.render(one.make_params(176, 104, frame=2, **kw))
+        want = one.read_radiance().copy()
+        assert same_bits(g.read_radiance(), want)
+        assert np.array_equal(g.read_rgba8(), one.read_rgba8())
+        g.render(g.make_params(96, 64, frame=7, **kw))           # another shape afterwards: buffers are re-made, results stay right
+        one.render(one.make_params(96, 64, frame=7, **kw))
+        assert same_bits(g.read_radiance(), one.read_radiance())
+    finally:
+        one.close(); g.close()
+
+
+@pytest.mark.parametrize("members", [2, 3])
+def test_group_renders_the_literal_packet_mode(rt, scene, members):
+    """PT_MODE_REFERENCE_PACKET through a group: 8x8 tiles are whole 2x2 packets (renderer.wgsl:359), so every packet belongs to one
+    member and the gathered image is the whole-frame packet image, bit for bit -- also at odd sizes, where edge packets have inactive lanes."""
+    g = rt.Group([0] * members, rt.PT_GROUP_TRANSPORT_COPY)
+    one = rt.Context(0)
+    try:
+        g.set_triangles(scene); g.build_bvh()
+        one.set_triangles(scene); one.build_bvh()
+        for (w, h) in ((208, 120), (97, 61), (8, 8)):
+            for cam, quat in (((0, 0, 2.5), (0, 0, 0, 1)), ((0.4, 0.2, 2.0), (0.02, 0.1, 0.0, 0.99478))):
+                one.render(one.make_params(w, h, cam, quat, mode=rt.PT_MODE_REFERENCE_PACKET))
+                want = one.read_radiance().copy()
+                g.render(g.make_params(w, h, cam, quat, mode=rt.PT_MODE_REFERENCE_PACKET))
+                assert same_bits(g.read_radiance(), want), (members, w, h)
+        # a plain context with a tile share of its own: the compact buffers of all ranks de-interleave to the same image
+        g.set_batch(2)
+        for f in range(2):
+            g.render(g.make_params(160, 96, mode=rt.PT_MODE_REFERENCE_PACKET))
+        one.render(one.make_params(160, 96, mode=rt.PT_MODE_REFERENCE_PACKET))
+        assert same_bits(g.read_radiance(), one.read_radiance())
+    finally:
+        one.close(); g.close()
+
+
 def test_group_rccl_transport_single_member(rt, scene):
     # ncclCommInitAll + ncclGather with world size 1: the RCCL calls themselves (librccl is opened here for the first time)
     g = rt.Group([0], rt.PT_GROUP_TRANSPORT_RCCL)

@@ -112,3 +112,27 @@ const PT=require(%r); const {Scene}=require(%r);
     out = subprocess.check_output([NODE, os.path.join(ROOT, "raytracer-public_amd", "js", "main.js"), "--devices", "0,0", "--transport", "copy", "--frames", "4", "--mode", "2",
                                    "--width", "320", "--height", "180", "--tris", "20000", "--dump", str(tmp_path / "d" / "BVH2.bin")], text=True)
     assert "Rendering on 2 GPUs" in out and "Msamples/s" in out
+
+
+@pytest.mark.gpu
+def test_node_accumulation_checkpoint_resumes(tmp_path):
+    """PathTracer.readAccumulation() / restoreAccumulation() (pt_read_accum / pt_set_accum through the addon): 3 accumulated frames, dump,
+    a NEW PathTracer with the same scene, restore, 3 more -- equal to 6 straight, bit for bit."""
+    glb = os.path.join(HERE, "golden", "steve.glb")
+    script = r"""
+const PT=require(%r); const {Scene}=require(%r);
+(async()=>{ const log=console.log; console.log=()=>{};
+ const opt={mode:PT.MODE_PATH,spp:2,maxBounces:3,seed:4,accumulate:true};
+ const s=new Scene(); await s.loadGLB(%r,{normalize:true,mode:'cube'});
+ const mk=async()=>{ const pt=new PT.PathTracer({width:120,height:72},opt); await pt.initialize(); await pt.setScene(s); pt.setCameraPosition(0.2,0.1,2.6); return pt; };
+ const a=await mk(); for (let f=0; f<6; f++) { a.setFrameCount(f); await a.render(); } const straight=a.readRadiance(); a.destroy();
+ const b=await mk(); for (let f=0; f<3; f++) { b.setFrameCount(f); await b.render(); } const dump=b.readAccumulation(); b.destroy();
+ const c=await mk(); c.restoreAccumulation(dump); for (let f=3; f<6; f++) { c.setFrameCount(f); await c.render(); } const resumed=c.readRadiance();
+ let threw=false; try { c.restoreAccumulation({width:120,height:72,samples:2,data:new Float32Array(8)}); } catch (e) { threw=/libmi355pt error 1/.test(e.message); }
+ c.destroy();
+ const u=new Uint32Array(straight.buffer), v=new Uint32Array(resumed.buffer); let same=u.length===v.length; for (let i=0; same && i<u.length; i++) same=u[i]===v[i];
+ log(JSON.stringify({same:same, samples:dump.samples, floats:dump.data.length, compact:dump.compact, w3:dump.data[3], threw:threw})); })().catch(e=>{console.error(e);process.exit(1);});
+""" % (os.path.join(ROOT, "raytracer-public_amd", "js", "PathTracer.js"), os.path.join(ROOT, "raytracer-public_amd", "js", "Scene.js"), glb)
+    info = json.loads(subprocess.check_output([NODE, "-e", script], text=True).strip().splitlines()[-1])
+    assert info == {"same": True, "samples": 6, "floats": 120 * 72 * 4, "compact": 0, "w3": 6, "threw": True}
+

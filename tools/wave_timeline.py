@@ -18,7 +18,7 @@ for rep in range(2):
         p.frame = 100 * rep + i; ctx.render(p)
     ctx.synchronize()
 print("frames in the launch: %d; ms (stats build): %.3f" % (B, ctx.last_render_ms()))
-buf = np.zeros((8192, 16), np.uint64); n = C.c_uint32()
+buf = np.zeros((8192, 24), np.uint64); n = C.c_uint32()
 rt.lib.pt_debug_wave_times(ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_uint32(8192), C.byref(n))
 w = buf[: n.value].astype(np.float64)
 t0 = w[:, 0].min()
@@ -38,6 +38,14 @@ print("total wave-iterations %.3fM, lane-steps %.1fM" % (w[:, 3].sum() / 1e6, w[
 tot = (w[:, 2] - w[:, 0]).sum() * 24.0   # 100 MHz ticks -> ~2.4 GHz cycles
 print('cycle shares of wave lifetime (s_memtime): shade %.1f%%, refill %.1f%%, traversal step %.1f%% (pre-exhaustion %.1f%%)' % tuple(100 * w[:, k].sum() / tot for k in (10, 11, 12, 13)))
 print('cycles per shade pass %.0f, per refill %.0f, per step pre %.0f, post %.0f' % (w[:, 10].sum() / w[:, 4].sum(), w[:, 11].sum() / w[:, 5].sum(), w[live, 13].sum() / pre_it.sum(), (w[live, 12] - w[live, 13]).sum() / post_it.sum()))
+rs = w[:, 16] > 0
+if rs.any():
+    t_rs = (w[rs, 16] - t0) / 100.0
+    it_1 = w[rs, 17] - w[rs, 6]; it_q = w[rs, 3] - w[rs, 17]              # iterations after the queue ran dry: one ray per lane / per quad
+    print("re-seated (one ray per quad): %d of %d wavefronts; at us: p10 %.0f p50 %.0f p90 %.0f; after queue-empty by us p50 %.0f" % (rs.sum(), n.value, *np.percentile(t_rs, [10, 50, 90]), np.median(t_rs - qe[rs])))
+    print("  iterations between queue-empty and re-seating p50 %d (us/iter p50 %.2f), in quad mode p50 %d max %d (us/iter p50 %.2f); rays per quad-mode wavefront-iteration %.2f" % (
+        np.median(it_1), np.median((t_rs - qe[rs]) / np.maximum(it_1, 1)), np.median(it_q), it_q.max(), np.median((end[rs] - t_rs) / np.maximum(it_q, 1)), (w[rs, 7] - w[rs, 18]).sum() / 4.0 / max(it_q.sum(), 1)))
+    print("  cycles per step: one ray per lane after queue-empty %.0f, quad mode %.0f" % ((w[rs, 19] - w[rs, 13]).sum() / max(it_1.sum(), 1), (w[rs, 12] - w[rs, 19]).sum() / max(it_q.sum(), 1)))
 st = ctx.stats(); print(st)
 order = np.argsort(end)[::-1][:12]
 print("slowest waves: end us | queue-empty us | iterations after | shade passes after | longest path that ended after (steps)")
@@ -48,5 +56,5 @@ print("iterations after queue-empty: p50 %d p90 %d p99 %d max %d; longest path e
       (tuple(np.percentile(post, [50, 90, 99, 100])) + tuple(np.percentile(w[live, 14], [50, 90, 99, 100]))))
 dbg = np.zeros(24, np.uint64); rt.lib.pt_debug_counters(ctx.h, dbg.ctypes.data_as(C.c_void_p))
 print('pushes %d, at depth>=8 %.2f%%, >=12 %.2f%%, spilled(>=kShort) %.3f%%' % (dbg[8], 100.0 * dbg[9] / dbg[8], 100.0 * dbg[10] / dbg[8], 100.0 * dbg[11] / dbg[8]))
-print('drain consolidation: %d paths handed over, %d fetched, %d lost; wavefronts: %d never registered, %d donors, %d collectors, %d without a slot' % tuple(int(dbg[k]) for k in (16, 17, 18, 19, 20, 21, 22)))
+print('wavefronts that re-seated their paths (one ray per quad of lanes): %d' % int(dbg[16]))
 print('longest path %d traversal steps, longest ray %d; paths >= 512 steps: %d, >= 1024: %d' % (dbg[12], dbg[13], dbg[14], dbg[15]))
