@@ -58,7 +58,7 @@ L2_PEAK_GBS, L2_LINE, HBM_PEAK_GBS = 34500.0, 128, 8000.0
 # requests, measured chip-wide by tools/probes/gather64.hip (profiles/r03_gather64_probe.txt, V0) -- 1.42 requests per cycle and CU
 L1_GATHER_PEAK_GREQ = 217.7 * 4
 PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")
-KERNEL_SOURCES = ["pt_megakernel.hip", "pt_device.h", "pt_kernels.h"]
+KERNEL_SOURCES = ["pt_megakernel.hip", "pt_megakernel_loop.inc", "pt_device.h", "pt_kernels.h"]
 VERIFY_STEP = 4         # the timed frame is checked on every 4th pixel in x and y (1/16 of the frame, ~0.6 s of oracle time)
 SHARD_PIECES = 4        # launches a sharded run is cut into at least (tools/shard_schedule_sim.py)
 

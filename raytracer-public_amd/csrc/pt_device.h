@@ -106,6 +106,10 @@ __device__ __forceinline__ RaySel ray_selectors(F3 inv) {
 }
 constexpr uint32_t kEmptyBox0 = 0x7C007C00u, kEmptyBox1 = 0xFC007C00u, kEmptyBox2 = 0xFC00FC00u;   // mn = +inf, mx = -inf (f16)
 // returns the hit mask of the wavefront's active lanes (the two comparisons are ballots of their own, combined on the scalar unit)
+// (Round 4 tried the 18 instructions up to max(tmin, 0) as ONE asm statement in a fixed order: on gfx950 the compiler puts an `s_nop 0` behind
+// every one-instruction asm statement -- it must assume a partial register write, the dst_sel forwarding hazard --, 24 idle issue slots per
+// node here.  The single statement removed them and measured 0.6 % SLOWER in dense launches, same-session (profiles/r04_q5_slab_asm_ab.txt):
+// the step is not bound by issue slots, and eleven early-clobber temporaries per box cost more than the no-ops.  Not kept.)
 __device__ __forceinline__ unsigned long long slab_sel(const F3& o, const F3& inv, const RaySel& sel, uint32_t w0, uint32_t w1, uint32_t w2, float best, float& tmin_out) {
     const uint32_t bx = __builtin_amdgcn_perm(w1, w0, sel.x), by = __builtin_amdgcn_perm(w2, w0, sel.y), bz = __builtin_amdgcn_perm(w2, w1, sel.z);
     const float nx = half_lo_minus(bx, o.x) * inv.x, ny = half_lo_minus(by, o.y) * inv.y, nz = half_lo_minus(bz, o.z) * inv.z;

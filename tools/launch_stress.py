@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Many launches per frame slot: tens of thousands of small path-traced frames without host waits (the drain consolidation's per-launch epoch runs
-through its 4,000-launch renewal in every slot), the same frame index at regular intervals compared bit for bit with the first rendering of it."""
+"""Many launches per frame slot: tens of thousands of small path-traced frames without host waits (every frame slot is reused thousands of times, every
+launch ends in the quad-mode drain), the same frame index at regular intervals compared bit for bit with the first rendering of it."""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)

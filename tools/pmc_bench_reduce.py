@@ -19,7 +19,7 @@ def _normalised_source(path):
 
 def source_tag():
     h = hashlib.sha256()
-    for f in ("pt_megakernel.hip", "pt_device.h", "pt_kernels.h"):
+    for f in ("pt_megakernel.hip", "pt_megakernel_loop.inc", "pt_device.h", "pt_kernels.h"):
         h.update(_normalised_source(os.path.join(ROOT, "raytracer-public_amd", "csrc", f)))
     return h.hexdigest()[:16]
 

@@ -2,7 +2,7 @@
 # One parameterised sweep instead of a script per question: time C2 (32-frame launches and one render() per frame) and C4 for every
 # value of one launch heuristic, in one gpurun session (box-to-box variance is ~10 %, so only numbers of one session compare).
 #   usage: tools/sweep.sh KNOB v1 v2 ...        KNOB = a PT_TUNE_* name without the prefix (SHADE FILL CHUNK ROWS XCD SLOTS
-#                                               GRIDDIV CONSOLIDATE CULL) or BUILD for -D flags (the library is rebuilt per value)
+#                                               GRIDDIV QUAD CULL) or BUILD for -D flags (the library is rebuilt per value)
 #   e.g.   gpurun -- 'tools/sweep.sh SHADE 8 16 24'      gpurun -- 'tools/sweep.sh BUILD "-DPT_SHORT_STACK=8" "-DPT_MEGA_WAVES_PER_SIMD=5"'
 cd $GRAFT_REPO_ROOT
 KNOB=$1; shift
