@@ -12,7 +12,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <deque>
 #include <string>
 #include <vector>
 
@@ -97,6 +96,7 @@ struct PtContext {
     // dense start of the next; the resolve passes stay in call order on the main stream.
     struct FrameSlot {
         hipStream_t side = nullptr; hipEvent_t resolved = nullptr, done = nullptr; bool used = false;
+        uint64_t resolved_seq = 0;                                      // launch sequence number of the latest record of `resolved` (pt_buffer_busy)
         DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<uint4> rays;
         // owned-tile slots that the launch in this slot traces (the others are culled: every camera ray misses the root box)
         DevBuf<uint32_t> trace_slots; uint32_t* h_trace = nullptr; size_t h_trace_cap = 0; hipEvent_t trace_copied = nullptr;
@@ -125,13 +125,15 @@ struct PtContext {
     std::vector<hipEvent_t> ring;    // start/stop pairs recorded by pt_render while timing is on
     uint32_t ring_used = 0;
     // pt_buffer_busy: the byte ranges that launches not yet known to be delivered write into.  Every launch appends its targets with its
-    // sequence number and records one event on the context's stream behind its last write (the resolve passes of consecutive launches
-    // are ordered there); ranges are dropped once their launch's event has completed -- whatever frame slot the launch ran in and
-    // however many launches were submitted after it.
+    // sequence number.  The context's stream is in order and every launch's last write is followed there by an event that exists anyway
+    // (the frame slot's `resolved`, re-recorded by the slot's next launch; `misc_fence` behind the kernels that do not use a slot), each
+    // remembering the sequence number of its LATEST record: once such an event has completed, every launch up to that number has been
+    // delivered -- whatever frame slot it ran in and however many launches were submitted after it.  (No event of its own per launch:
+    // one more marker on the stream cost the reference's 0.16 ms frame 18 % with one render() per launch.)
     struct InFlight { const char* lo; const char* hi; uint64_t seq; };
-    struct Fence { uint64_t seq; hipEvent_t ev; };
-    std::vector<InFlight> inflight; std::deque<Fence> fences; std::vector<hipEvent_t> fence_pool;
-    uint64_t launch_seq = 0;
+    std::vector<InFlight> inflight;
+    uint64_t launch_seq = 0, delivered_seq = 0;
+    hipEvent_t misc_fence = nullptr; uint64_t misc_fence_seq = 0;
 };
 
 namespace {
@@ -156,22 +158,27 @@ uint32_t accum_share_key(uint32_t rank, uint32_t count, bool compact) { return (
 
 // ---- pt_buffer_busy bookkeeping (PtContext::inflight) ----
 void prune_inflight(PtContext* ctx) {
-    uint64_t delivered = 0; bool any = false;
-    while (!ctx->fences.empty()) {
-        const hipError_t q = hipEventQuery(ctx->fences.front().ev);
-        if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }       // an answer, not an error: do not leave it behind for the launch checks
-        delivered = ctx->fences.front().seq; any = true;                     // complete (or failed: nothing will be written any more)
-        ctx->fence_pool.push_back(ctx->fences.front().ev); ctx->fences.pop_front();
+    if (ctx->inflight.empty()) return;
+    uint64_t delivered = ctx->delivered_seq;
+    auto done = [&](hipEvent_t ev) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); return false; }         // an answer, not an error: do not leave it behind for the launch checks
+        return true;                                                                  // complete (or failed: nothing will be written any more)
+    };
+    for (auto& sl : ctx->slots) if (sl.side && sl.used && sl.resolved_seq > delivered && done(sl.resolved)) delivered = sl.resolved_seq;
+    if (ctx->misc_fence && ctx->misc_fence_seq > delivered && done(ctx->misc_fence)) delivered = ctx->misc_fence_seq;
+    if (delivered != ctx->delivered_seq) {
+        ctx->delivered_seq = delivered;
+        ctx->inflight.erase(std::remove_if(ctx->inflight.begin(), ctx->inflight.end(), [&](const PtContext::InFlight& f) { return f.seq <= delivered; }), ctx->inflight.end());
     }
-    if (any) ctx->inflight.erase(std::remove_if(ctx->inflight.begin(), ctx->inflight.end(), [&](const PtContext::InFlight& f) { return f.seq <= delivered; }), ctx->inflight.end());
 }
 void everything_delivered(PtContext* ctx) {         // after a host wait on the context's stream
-    for (auto& f : ctx->fences) ctx->fence_pool.push_back(f.ev);
-    ctx->fences.clear(); ctx->inflight.clear();
+    ctx->delivered_seq = ctx->launch_seq; ctx->inflight.clear();
 }
-// the launch just submitted writes `bytes` bytes at each of targets[0..n): remembered until an event recorded here, behind it, completes
-int track_targets(PtContext* ctx, float4* const* targets, uint32_t n, size_t bytes) {
-    prune_inflight(ctx);
+// the launch just submitted writes `bytes` bytes at each of targets[0..n): remembered until an event recorded behind it on the context's
+// stream has completed; returns the launch's sequence number (the caller stores it next to the event it records)
+uint64_t track_targets(PtContext* ctx, float4* const* targets, uint32_t n, size_t bytes) {
+    if (ctx->inflight.size() >= 64) prune_inflight(ctx);                 // bounded without a query per launch
     const uint64_t seq = ++ctx->launch_seq;
     for (uint32_t i = 0; i < n; ++i) {
         if (!targets[i]) continue;
@@ -179,12 +186,7 @@ int track_targets(PtContext* ctx, float4* const* targets, uint32_t n, size_t byt
         for (uint32_t g = 0; g < i && !dup; ++g) dup = targets[g] == targets[i];
         if (!dup) ctx->inflight.push_back({(const char*)targets[i], (const char*)targets[i] + bytes, seq});
     }
-    hipEvent_t ev = nullptr;
-    if (!ctx->fence_pool.empty()) { ev = ctx->fence_pool.back(); ctx->fence_pool.pop_back(); }
-    else PT_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    PT_HIP(ctx, hipEventRecord(ev, ctx->stream));
-    ctx->fences.push_back({seq, ev});
-    return PT_OK;
+    return seq;
 }
 
 // Triangle records (64 B each), then one all-zero record (what a leaf with an out-of-range triangle index points at: never hit).
@@ -474,7 +476,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.done, 0));
     PT_HIP(ctx, ptk::launch_resolve(A, ctx->stream));
     PT_HIP(ctx, hipEventRecord(sl.resolved, ctx->stream)); sl.used = true;
-    if (int rc = track_targets(ctx, ctx->pending_outs.data(), nf, (A.compact ? size_t(A.num_tiles) * 64u : size_t(A.width) * A.height) * sizeof(float4))) return rc;
+    sl.resolved_seq = track_targets(ctx, ctx->pending_outs.data(), nf, (A.compact ? size_t(A.num_tiles) * 64u : size_t(A.width) * A.height) * sizeof(float4));
     if (!ring) PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
     if (ring) ctx->ring_used += 2;
     ctx->timed = !ring;
@@ -549,8 +551,7 @@ void pt_destroy(PtContext* ctx) {
         if (sl.side) { (void)hipStreamSynchronize(sl.side); (void)hipStreamDestroy(sl.side); }
     }
     for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
-    for (auto& f : ctx->fences) (void)hipEventDestroy(f.ev);
-    for (hipEvent_t e : ctx->fence_pool) (void)hipEventDestroy(e);
+    if (ctx->misc_fence) (void)hipEventDestroy(ctx->misc_fence);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -982,7 +983,12 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
         PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
         PT_HIP(ctx, ptk::launch_render(A, kmode, stats, ctx->stream));
         PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
-        { float4* t = A.out; if (int rc = track_targets(ctx, &t, 1, (A.compact ? size_t(A.num_tiles) * 64u : npx) * sizeof(float4))) return rc; }
+        {   // these kernels use no frame slot: their own fence for pt_buffer_busy
+            float4* t = A.out;
+            if (!ctx->misc_fence) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->misc_fence, hipEventDisableTiming));
+            PT_HIP(ctx, hipEventRecord(ctx->misc_fence, ctx->stream));
+            ctx->misc_fence_seq = track_targets(ctx, &t, 1, (A.compact ? size_t(A.num_tiles) * 64u : npx) * sizeof(float4));
+        }
     }
     if (ring) ctx->ring_used += 2;
     ctx->timed = !ring;

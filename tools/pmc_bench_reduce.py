@@ -25,12 +25,14 @@ def source_tag():
 
 
 per_frame, launches_seen = collections.OrderedDict(), {}
+builder_busy_all = None
 steps = None
 for p in sorted(glob.glob(os.path.join(out_dir, "pass*/"))):
     n = os.path.basename(os.path.dirname(p))[4:]
     log = json.load(open(os.path.join(out_dir, "launch_log_pass%s.json" % n)))
     steps = log["steps"]
-    timed = [k for k, (tag, nf) in enumerate(log["launches"]) if tag == "timed"]
+    timed = [k for k, (tag, nf) in enumerate(log["launches"]) if tag.startswith("timed")]      # every repetition of the timed region ("timed", "timed-rep1", ...): the same K frames each
+    reps = max(1, len({tag for tag, nf in log["launches"] if tag.startswith("timed")}))
     rows = collections.OrderedDict()          # counter -> {dispatch id: value}; dispatch ids grow in submission order
     for f in glob.glob(p + "**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
@@ -42,8 +44,8 @@ for p in sorted(glob.glob(os.path.join(out_dir, "pass*/"))):
         if len(vals) != len(log["launches"]):
             print("pass %s: %d dispatches of %s, launch log has %d -- skipped" % (n, len(vals), KERNEL, len(log["launches"])))
             continue
-        per_frame[name] = sum(vals[k] for k in timed) / steps
-        launches_seen[name] = len(timed)
+        per_frame[name] = sum(vals[k] for k in timed) / steps / reps             # mean over the repetitions
+        launches_seen[name] = len(timed) // reps
 stats = {}
 for f in glob.glob(os.path.join(out_dir, "trace/**/*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
@@ -62,23 +64,31 @@ try:
                 spans.append((int(row["Dispatch_Id"]), int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
     spans.sort()
     if len(spans) == len(log["launches"]):
-        iv = sorted((a, b) for k, (_, a, b) in enumerate(spans) if log["launches"][k][0] == "timed")
-        total, cur_a, cur_b = 0, None, None
-        for a, b in iv:
-            if cur_b is None or a > cur_b:
-                if cur_b is not None:
-                    total += cur_b - cur_a
-                cur_a, cur_b = a, b
-            else:
-                cur_b = max(cur_b, b)
-        if cur_b is not None:
-            total += cur_b - cur_a
-        builder_busy = total / 1e6 / log["steps"]
+        def union_ns(iv):
+            total, cur_a, cur_b = 0, None, None
+            for a, b in sorted(iv):
+                if cur_b is None or a > cur_b:
+                    if cur_b is not None:
+                        total += cur_b - cur_a
+                    cur_a, cur_b = a, b
+                else:
+                    cur_b = max(cur_b, b)
+            if cur_b is not None:
+                total += cur_b - cur_a
+            return total
+        per_rep = collections.OrderedDict()            # busy time of every repetition of the timed region; the MEDIAN one is what bench.py reports as well
+        for k, (_, a, b) in enumerate(spans):
+            tag = log["launches"][k][0]
+            if tag.startswith("timed"):
+                per_rep.setdefault(tag, []).append((a, b))
+        busy = sorted(union_ns(iv) / 1e6 / log["steps"] for iv in per_rep.values())
+        builder_busy = busy[(len(busy) - 1) // 2]
+        builder_busy_all = busy
     else:
         print("kernel trace: %d dispatches of %s, launch log has %d -- no builder-side busy time" % (len(spans), KERNEL, len(log["launches"])))
 except Exception as e:
     print("no builder-side busy time:", e)
-res = {"command": command, "builder_kernel_busy_ms_per_frame": builder_busy, "source_tag": source_tag(), "kernel": KERNEL, "steps": steps,
+res = {"command": command, "builder_kernel_busy_ms_per_frame": builder_busy, "builder_kernel_busy_ms_per_frame_all_reps": builder_busy_all, "source_tag": source_tag(), "kernel": KERNEL, "steps": steps,
        "frames_per_launch": steps / max(launches_seen.get("SQ_INSTS_VALU", 1), 1), "timed_launches": launches_seen.get("SQ_INSTS_VALU"),
        "per_frame": per_frame, "kernel_stats": stats,
        "how": "tools/pmc_bench.sh: one rocprofv3 --pmc pass per counter group over the command above; the timed launches are identified by "

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential soak of the hot path: the persistent megakernel under random scenes, cameras,
-resolutions, spp / bounce counts, tile shares, batch sizes and accumulation against the one-pixel-per-lane
+resolutions, spp / bounce counts, tile shares, batch sizes, accumulation and quad-mode thresholds against the one-pixel-per-lane
 kernel (a second, independent HIP implementation that the parity tests pin to the oracle), bit for bit.
 
 usage: python tools/soak.py [seconds] [seed]        (exit code 1 and the failing configuration on a mismatch)"""
@@ -55,7 +55,10 @@ def main():
             count = int(rng.choice([1, 1, 2, 3, 4, 8])) if not accumulate else 1
             batch = int(rng.integers(1, 13)) if rng.random() < 0.8 else int(rng.integers(13, 33))
             sd = int(rng.integers(0, 2 ** 31))
-            cfg = dict(kind=kind, n=n, w=w, h=h, spp=spp, bounces=bounces, nf=nf, accumulate=accumulate, count=count, batch=batch, seed=sd)
+            # the drain's quad mode at its default and at odd thresholds (paths a wavefront may hold when it re-seats them; 0 = never)
+            quad = int(rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 16, 9, 4, 1, 0]))
+            ctx.debug_set_tune("QUAD", quad)
+            cfg = dict(kind=kind, n=n, w=w, h=h, spp=spp, bounces=bounces, nf=nf, accumulate=accumulate, count=count, batch=batch, seed=sd, quad=quad)
             kw = dict(mode=rt.PT_MODE_PATH, spp=spp, max_bounces=bounces, seed=sd)
 
             def params(f, **extra):
