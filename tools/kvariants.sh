@@ -8,6 +8,9 @@ run() { "$@" 2>&1 | tail -1; }
 for V in "$@"; do
   echo "== variant: ${V:-<default>}" >> $OUT
   make -s -B -j8 -C raytracer-public_amd/csrc EXTRA="$V" 2>&1 | grep -E "error" >> $OUT && continue
+  # the build under test is bit-exact before it is timed (a wrong kernel's time means nothing)
+  if [ -n "$KV_FULL" ]; then timeout -k 10 400 python3 -m pytest tests -m gpu -q -x 2>&1 | tail -1 >> $OUT       # KV_FULL=1: the whole GPU suite per variant
+  else timeout -k 10 200 python3 -m pytest tests/test_gpu_parity.py -q -x -k "path_mode_bit_exact or sponza_class or stack_overflow or quad_mode" 2>&1 | tail -1 >> $OUT; fi
   { echo -n "batch32   "; PB_BATCH=32 PB_VARY=1 run python3 tools/pipeline_bench.py 128
     echo -n "solo20    "; PB_SOLO=1 PB_BATCH=20 PB_VARY=1 run python3 tools/pipeline_bench.py 80
     echo -n "solo1     "; PB_SOLO=1 PB_BATCH=1 PB_VARY=1 run python3 tools/pipeline_bench.py 40
