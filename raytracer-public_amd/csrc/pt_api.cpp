@@ -41,16 +41,16 @@ struct DevBuf {
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto,
-             slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto, fault = kAuto;
+             slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}, {"FAULT", &PtTune::fault}};
+            {"FILL", &PtTune::fill}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL", "STATSBATCH", "QUAD", "FAULT"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL", "STATSBATCH", "QUAD"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -97,7 +97,7 @@ struct PtContext {
     struct FrameSlot {
         hipStream_t side = nullptr; hipEvent_t resolved = nullptr, done = nullptr; bool used = false;
         uint64_t resolved_seq = 0;                                      // launch sequence number of the latest record of `resolved` (pt_buffer_busy)
-        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<uint4> rays; DevBuf<unsigned long long> pool;
+        DevBuf<uint32_t> queue; DevBuf<float4> samples; DevBuf<uint2> spill; DevBuf<uint4> rays;
         // owned-tile slots that the launch in this slot traces (the others are culled: every camera ray misses the root box)
         DevBuf<uint32_t> trace_slots; uint32_t* h_trace = nullptr; size_t h_trace_cap = 0; hipEvent_t trace_copied = nullptr;
         uint32_t cull_key[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t num_trace_tiles = 0; bool cull_valid = false;
@@ -134,9 +134,6 @@ struct PtContext {
     std::vector<InFlight> inflight;
     uint64_t launch_seq = 0, delivered_seq = 0;
     hipEvent_t misc_fence = nullptr; uint64_t misc_fence_seq = 0;
-    // kernel-side faults (RenderArgs::fault): one word in mapped pinned host memory that a wavefront sets when it gives up a wait; looked at
-    // behind every host wait on the context's stream (no copy, no cost while nothing happens)
-    uint32_t* h_fault = nullptr; uint32_t* d_fault = nullptr;
 };
 
 namespace {
@@ -177,15 +174,6 @@ void prune_inflight(PtContext* ctx) {
 }
 void everything_delivered(PtContext* ctx) {         // after a host wait on the context's stream
     ctx->delivered_seq = ctx->launch_seq; ctx->inflight.clear();
-}
-// after a host wait: did a wavefront of one of the launches that have just completed give up a wait?  (The result it belongs to is incomplete.)
-int check_fault(PtContext* ctx, const char* where) {
-    if (!ctx->h_fault) return PT_OK;
-    const uint32_t code = *(volatile uint32_t*)ctx->h_fault;
-    if (code == 0u) return PT_OK;
-    *(volatile uint32_t*)ctx->h_fault = 0u;
-    return fail(ctx, PT_ERR_HIP, std::string(where) + ": trace_paths_kernel reported fault " + std::to_string(code) +
-                " (a wavefront waited for a hand-over of paths that never completed; the frames of the launches just finished are incomplete)");
 }
 // the launch just submitted writes `bytes` bytes at each of targets[0..n): remembered until an event recorded behind it on the context's
 // stream has completed; returns the launch's sequence number (the caller stores it next to the event it records)
@@ -415,7 +403,6 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         PT_HIP(ctx, s.samples.ensure(cap_samples));
         PT_HIP(ctx, s.spill.ensure(size_t(full_lanes) * size_t(64 - PT_SHORT_STACK)));
         PT_HIP(ctx, s.rays.ensure(size_t(full_lanes) * 3u));          // 64 ray records of 3 x uint4 per wavefront
-        if (PT_MERGE) PT_HIP(ctx, s.pool.ensure(size_t(full_lanes / 64u) * ptk::kPoolSlots * ptk::kPoolWords));     // drain merge: an inbox of path records per wavefront
         PT_HIP(ctx, s.frame_params.ensure(std::max<size_t>(ctx->batch_size, nf))); PT_HIP(ctx, s.frame_outs.ensure(std::max<size_t>(ctx->batch_size, nf)));
         if (s.primed_ptr != (const void*)s.samples.ptr || s.primed_samples < cap_samples) {
             if (s.used) PT_HIP(ctx, hipStreamWaitEvent(s.side, s.resolved, 0));
@@ -425,8 +412,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     }
     PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(want_slots))];
     A.prime = stats ? 1u : 0u;                   // instrumented launches start from a freshly primed prefix
-    A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.raybuf = sl.rays.ptr; A.pool = sl.pool.ptr;
-    A.fault = ctx->d_fault; A.fault_inject = PtTune::pick(ctx->tune.fault, 0u);
+    A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.raybuf = sl.rays.ptr;
     A.trace_slots = nullptr;
     if (cull) {
         // the list travels through a pinned staging buffer of the slot; it is rebuilt only when the rectangle (or the tile share) changes
@@ -510,16 +496,8 @@ extern "C" {
 
 #define PT_STR2(x) #x
 #define PT_STR(x) PT_STR2(x)
-// names the build options that change what the megakernel does (tests look for "merge" before they ask for the hand-over watchdog)
-const char* pt_version(void) {
-    return "mi355pt 0.1 (gfx950; workgroup " PT_STR(PT_MEGA_BLOCK) ", quad " PT_STR(PT_QUAD) ", "
-#if PT_MERGE && PT_MEGA_BLOCK > 64 && PT_QUAD == 1
-           "drain merge"
-#else
-           "no drain merge"
-#endif
-           ")";
-}
+// names the build options that change what the megakernel does
+const char* pt_version(void) { return "mi355pt 0.1 (gfx950; workgroup " PT_STR(PT_MEGA_BLOCK) ", quad " PT_STR(PT_QUAD) ")"; }
 
 const char* pt_last_error(const PtContext* ctx) { return ctx ? ctx->err.c_str() : g_global_error.c_str(); }
 
@@ -547,8 +525,6 @@ int pt_create(int device_ordinal, PtContext** out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop);
     if (e == hipSuccess) e = ctx->d_stats.ensure(24);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_fault, 64, hipHostMallocMapped);
-    if (e == hipSuccess) { *ctx->h_fault = 0u; e = hipHostGetDevicePointer((void**)&ctx->d_fault, ctx->h_fault, 0); }
     if (e == hipSuccess) { hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, dev); if (e == hipSuccess) ctx->num_cus = prop.multiProcessorCount; }
     if (e != hipSuccess) { int rc = fail_hip(nullptr, e, "pt_create"); pt_destroy(ctx); return rc; }
     ctx->stream = ctx->own_stream;
@@ -569,9 +545,8 @@ void pt_destroy(PtContext* ctx) {
     ctx->d_bounds.release(); ctx->d_counters.release(); ctx->d_code_tmp.release(); ctx->d_index_tmp.release(); ctx->d_node2.release();
     ctx->d_subtree.release(); ctx->d_ids.release(); ctx->d_bnd.release(); ctx->d_child_pos.release(); ctx->d_build_temp.release();
     if (ctx->h_word) (void)hipHostFree(ctx->h_word);
-    if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
     for (auto& sl : ctx->slots) {
-        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.rays.release(); sl.pool.release(); sl.trace_slots.release();
+        sl.queue.release(); sl.samples.release(); sl.spill.release(); sl.rays.release(); sl.trace_slots.release();
         if (sl.h_trace) (void)hipHostFree(sl.h_trace);
         if (sl.trace_copied) (void)hipEventDestroy(sl.trace_copied); sl.frame_params.release(); sl.frame_outs.release();
         if (sl.resolved) (void)hipEventDestroy(sl.resolved);
@@ -607,7 +582,7 @@ int pt_synchronize(PtContext* ctx) {
     if (int rc = flush_pending(ctx)) return rc;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     everything_delivered(ctx);
-    return check_fault(ctx, "pt_synchronize");
+    return PT_OK;
 }
 
 // ---- host-side scene build ------------------------------------------------------------
@@ -1131,7 +1106,7 @@ int pt_read_radiance(PtContext* ctx, float* dst, uint64_t dst_floats) {
     if (dst_floats < need) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_radiance: destination too small");
     PT_HIP(ctx, hipMemcpyAsync(dst, ctx->last_full, need * 4, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return check_fault(ctx, "pt_read_radiance");
+    return PT_OK;
 }
 
 int pt_read_rgba8(PtContext* ctx, uint8_t* dst, uint64_t dst_bytes) {
@@ -1144,7 +1119,7 @@ int pt_read_rgba8(PtContext* ctx, uint8_t* dst, uint64_t dst_bytes) {
     PT_HIP(ctx, ptk::launch_rgba8(ctx->last_full, ctx->d_u32tmp.ptr, uint32_t(npx), ctx->stream));
     PT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_u32tmp.ptr, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return check_fault(ctx, "pt_read_rgba8");
+    return PT_OK;
 }
 
 int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t dst_bytes) {
@@ -1157,7 +1132,7 @@ int pt_read_tonemapped(PtContext* ctx, int from_rgba8, uint8_t* dst, uint64_t ds
     PT_HIP(ctx, ptk::launch_tonemap(ctx->last_full, ctx->d_u32tmp.ptr, ctx->out_w, ctx->out_h, from_rgba8, ctx->stream));
     PT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_u32tmp.ptr, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return check_fault(ctx, "pt_read_tonemapped");
+    return PT_OK;
 }
 
 // ---- checkpoint / resume of a progressive accumulation -------------------------------------------------------------------------

@@ -29,20 +29,12 @@
 #ifndef PT_QUAD_LIVE
 #define PT_QUAD_LIVE 16            // paths a wavefront may hold when it re-seats them (16 quads per wavefront)
 #endif
-#ifndef PT_MERGE
-#define PT_MERGE (PT_MEGA_BLOCK > 64 ? 1 : 0)   // wavefronts of a workgroup in quad mode hand ALL their paths to a sibling with room for them and leave (needs multi-wave workgroups: shared LDS)
-#endif
-#ifndef PT_MERGE_MAX
-#define PT_MERGE_MAX 8             // a wavefront tries to hand its paths over once it holds at most this many
-#endif
 #ifndef PT_FILL_THRESHOLD
 #define PT_FILL_THRESHOLD 4        // hand out ready camera rays when this many lanes of a wavefront are without a path (a fetch from the ray buffer is cheap: 4 beats 8 by 2 %)
 #endif
 
 namespace ptk {
 
-constexpr uint32_t kFaultHandOver = 1;    // RenderArgs::fault: a wavefront left with records reserved in its inbox that never became complete
-constexpr uint32_t kPoolSlots = 32, kPoolWords = 16;      // drain merge: inbox records per wavefront (a ring), 64-bit words per record (128 bytes)
 constexpr uint32_t kWaveTimeWords = 24;  // STATS diagnostics: 64-bit words per wavefront in RenderArgs::wave_times
 #define PT_MAX_BATCH 256    // frames per persistent launch (their per-frame parameters live in a small device array)
 // Per-frame part of the UBO for a batched launch (several consecutive frames traced by one persistent launch).
@@ -90,9 +82,6 @@ struct RenderArgs {
     float4*   samples;          // per-sample radiance, item = (slot*spp + s)*64 + lane_in_tile; primed per batch by the trace (camera-ray generation), read by resolve_kernel
     uint32_t* queue;            // global item cursor
     uint2*    spill;            // deep stack entries: [entry][grid lane]
-    uint32_t* fault;            // host-visible (mapped pinned) word: set to a PT_FAULT_* code by a wavefront that gave up waiting -- the host turns it into an error at its next wait
-    uint32_t  fault_inject;     // diagnostics (knob FAULT): givers of the drain merge reserve and never publish, so that the takers' watchdog fires
-    unsigned long long* pool;   // drain merge (PT_MERGE): per wavefront of the grid an inbox of kPoolSlots path records of kPoolWords 64-bit words
     uint4*    raybuf;           // per wavefront of the grid: 64 camera-ray records of 3 x uint4 (o, d, inv, key, sample index), generated 64 at a time
     unsigned long long* wave_times;   // STATS diagnostics: kWaveTimeWords words per wave (begin, queue-empty, end ticks @100 MHz, loop counts, ...)
     // Queue enumeration vs sample storage.  The queue hands out (frame, traced tile, sample) batches of 64 pixel-samples;

@@ -434,29 +434,3 @@ def test_packed_shares_rebuild_every_frame(rt, gpu_ctx, w, h, world, cam, spp):
             gpu_ctx.unpack_batch(p_ptr.value, frames * pstride, pstride, frames, w, h, world, (0, 0, tiles_x + 1, tiles_y), spp)     # rectangle outside the image
     finally:
         hip.hipFree(c_ptr); hip.hipFree(p_ptr); hip.hipFree(f_ptr)
-
-
-
-def test_kernel_side_fault_reaches_the_host(rt):
-    """a wait inside the kernel that gives up must not be silent.  The only such wait is the drain merge's -- a
-    wavefront leaving while records reserved in its inbox never became complete.  The FAULT knob makes givers reserve and never publish;
-    the takers' watchdog fires, the launch still ends, and the next host wait returns PT_ERR_HIP with a message (the frame is incomplete,
-    and the error says so); afterwards the context works as before."""
-    if b"no drain merge" in rt.lib.pt_version():
-        pytest.skip("library built without the drain merge (single-wave workgroups): the kernel has no wait that can give up")
-    ctx = rt.Context(0)
-    try:
-        tris = rt.procedural_scene(0, 30000)
-        ctx.set_triangles(tris); ctx.build_bvh()
-        p = ctx.make_params(640, 360, mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, seed=2)
-        ctx.render(p); want = ctx.read_radiance().copy()
-        ctx.debug_set_tune("FAULT", 1)
-        ctx.render(p)
-        with pytest.raises(rt.PtError) as e:
-            ctx.synchronize()
-        assert "fault" in str(e.value) and "hand-over" in str(e.value)
-        ctx.debug_set_tune("FAULT")
-        ctx.render(p)
-        assert same_bits(ctx.read_radiance(), want)                  # the fault was reported once; the context is usable
-    finally:
-        ctx.close()

@@ -56,6 +56,6 @@ print("iterations after queue-empty: p50 %d p90 %d p99 %d max %d; longest path e
       (tuple(np.percentile(post, [50, 90, 99, 100])) + tuple(np.percentile(w[live, 14], [50, 90, 99, 100]))))
 dbg = np.zeros(24, np.uint64); rt.lib.pt_debug_counters(ctx.h, dbg.ctypes.data_as(C.c_void_p))
 print('pushes %d, at depth>=8 %.2f%%, >=12 %.2f%%, spilled(>=kShort) %.3f%%' % (dbg[8], 100.0 * dbg[9] / dbg[8], 100.0 * dbg[10] / dbg[8], 100.0 * dbg[11] / dbg[8]))
-print('wavefronts that re-seated their paths (one ray per quad of lanes): %d; drain merge: %d paths handed to a sibling, %d taken from an inbox' % (int(dbg[16]), int(dbg[17]), int(dbg[18])))
+print('wavefronts that re-seated their paths (one ray per quad of lanes): %d' % int(dbg[16]))
 print('wavefronts still running at us after the first began: ' + ', '.join('%d: %d' % (t, int((end > t).sum())) for t in np.percentile(end, [10, 30, 50, 70, 90, 97]).astype(int)))
 print('longest path %d traversal steps, longest ray %d; paths >= 512 steps: %d, >= 1024: %d' % (dbg[12], dbg[13], dbg[14], dbg[15]))
