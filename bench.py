@@ -19,8 +19,8 @@ overlaps the trace of launch b+1.  Total work per step is fixed -> "scaling": "s
 Every run checks one TIMED frame against the CPU oracle on a fixed pixel grid (every 4th pixel in x and y, all samples,
 bit for bit) and prints "verified": true; a mismatch ends the run with a non-zero status and no result line.
 
-The timed region (exactly K steps between barriers + synchronisations, max over ranks) is repeated --reps times (default 3,
-SURVEY 8d) after the warm-up; `value` / `ms_per_step` are the MEDIAN repetition, `ms_per_step_min_max` the spread.
+The timed region (exactly K steps between barriers + synchronisations, max over ranks) is repeated --reps times (default 5;
+SURVEY 8d asks for at least 3) after the warm-up; `value` / `ms_per_step` are the MEDIAN repetition, `ms_per_step_min_max` the spread.
 
 The JSON line's `roofline` carries the fractions of the four resources a gather-and-compute kernel can be bound by and names the
 largest as `bound` (the vector L1's request rate since round 3, vector-instruction issue next), each with the
@@ -214,7 +214,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--reps", type=int, default=3, help="repetitions of the timed region (value = the median one)")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region (value = the median one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C4 leg of the `configs` block")
     ap.add_argument("--width", type=int, default=WIDTH)
