@@ -82,6 +82,21 @@ int main() {
         for (uint32_t r = 0; r < count; ++r) { pt::tile_list(100, 60, r, count, tl); total += tl.size(); }
         CHECK(total == 13 * 8, "tile lists partition the frame");
     }
+    // packed tile shares: the closed-form count of a rank's tiles inside a tile rectangle against plain enumeration, and the ranks partition the rectangle
+    for (uint32_t count : {1u, 2u, 3u, 5u, 8u})
+        for (uint32_t trial = 0; trial < 40; ++trial) {
+            const uint32_t tx = 13, ty = 8;
+            uint32_t a = (trial * 7u) % (tx + 1), b = (trial * 11u + 3u) % (tx + 1), c = (trial * 5u) % (ty + 1), d = (trial * 3u + 1u) % (ty + 1);
+            const uint32_t rect[4] = {a < b ? a : b, c < d ? c : d, a < b ? b : a, c < d ? d : c};
+            uint32_t sum = 0;
+            for (uint32_t r = 0; r < count; ++r) {
+                uint32_t brute = 0;
+                for (uint32_t y = rect[1]; y < rect[3]; ++y) for (uint32_t x = rect[0]; x < rect[2]; ++x) brute += ((x + y) % count == r) ? 1u : 0u;
+                CHECK(pt::rect_tile_count_of(r, count, rect) == brute, "rect_tile_count_of == enumeration");
+                sum += brute;
+            }
+            CHECK(sum == (rect[2] - rect[0]) * (rect[3] - rect[1]), "the ranks' tiles partition the rectangle");
+        }
     std::printf(fails ? "%d failures\n" : "host_sanitize ok\n", fails);
     return fails ? 1 : 0;
 }
