@@ -41,16 +41,16 @@ struct DevBuf {
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto,
-             slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto;
+             slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto, fork = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}};
+            {"FILL", &PtTune::fill}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}, {"FORK", &PtTune::fork}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL", "STATSBATCH", "QUAD"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL", "STATSBATCH", "QUAD", "FORK"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -372,6 +372,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     }
     A.shade_threshold = PtTune::pick(ctx->tune.shade, PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD);
     A.quad_live = std::min(16u, PtTune::pick(ctx->tune.quad, PT_QUAD_LIVE));     // 16 quads per wavefront
+    A.fork_shadow = PtTune::pick(ctx->tune.fork, PT_FORK_SHADOW);
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
     // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
     // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small

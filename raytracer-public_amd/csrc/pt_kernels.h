@@ -26,6 +26,9 @@
 #ifndef PT_QUAD
 #define PT_QUAD 1                  // 1: a wavefront with nothing left to start and at most PT_QUAD_LIVE paths goes on with one ray per quad of lanes (pt_megakernel.hip); 0: never; 2: quads from the first ray on (A/B builds)
 #endif
+#ifndef PT_FORK_SHADOW
+#define PT_FORK_SHADOW 1          // quad mode: a path hands its shadow ray to an idle quad of its wavefront and goes on with the next bounce at once (pt_megakernel.hip)
+#endif
 #ifndef PT_QUAD_LIVE
 #define PT_QUAD_LIVE 16            // paths a wavefront may hold when it re-seats them (16 quads per wavefront)
 #endif
@@ -98,6 +101,7 @@ struct RenderArgs {
     uint32_t  num_batches, perm_cols;     // real (frame, traced tile, sample) batches of the queue; columns of the batch transpose
     uint32_t  perm_rows, perm_rows_magic; // its rows and floor(2^32 / rows) for the division
     uint32_t  shade_threshold, fill_threshold;
+    uint32_t  fork_shadow;      // quad mode: shadow rays of paths that go on are traced by idle quads, next to the path's next ray (0: by the path itself, in turn)
     uint32_t  quad_live;        // re-seat the paths one per quad once the wavefront has nothing left to start and holds at most this many (0: never)
     // batched launch: frames[i] / outs[i] for i < num_frames; items of frame i are batches [i*batches_per_frame, ...)
     const FrameParams* frames; float4* const* outs;     // device arrays of the frame slot, filled by launch_frame_params

@@ -59,3 +59,5 @@ print('pushes %d, at depth>=8 %.2f%%, >=12 %.2f%%, spilled(>=kShort) %.3f%%' % (
 print('wavefronts that re-seated their paths (one ray per quad of lanes): %d' % int(dbg[16]))
 print('wavefronts still running at us after the first began: ' + ', '.join('%d: %d' % (t, int((end > t).sum())) for t in np.percentile(end, [10, 30, 50, 70, 90, 97]).astype(int)))
 print('longest path %d traversal steps, longest ray %d; paths >= 512 steps: %d, >= 1024: %d' % (dbg[12], dbg[13], dbg[14], dbg[15]))
+print('paths >= 512 steps: %.1f %% of their traversal steps belong to shadow rays (%d of %d)' % (100.0 * dbg[17] / max(int(dbg[18]), 1), dbg[17], dbg[18]))
+print('quad mode: shadow rays handed to an idle quad %d, no idle quad %d, paths that waited for their shadow ray %d; shadow rays in all %d' % (dbg[19], dbg[20], dbg[21], st['rays_shadow']))
