@@ -22,9 +22,9 @@ bit for bit) and prints "verified": true; a mismatch ends the run with a non-zer
 The timed region (exactly K steps between barriers + synchronisations, max over ranks) is repeated --reps times (default 5;
 SURVEY 8d asks for at least 3) after the warm-up; `value` / `ms_per_step` are the MEDIAN repetition, `ms_per_step_min_max` the spread.
 
-The JSON line's `roofline` carries the fractions of the four resources a gather-and-compute kernel can be bound by and names the
-largest as `bound` (the vector L1's request rate since round 3, vector-instruction issue next), each with the
-source of its peak (`peak_source`: "guide" = /opt/skills/guides/MI355X_MICROARCH.md, "probe" = measured by tools/probes/), with the
+The JSON line's `roofline` carries the fractions of the four resources a gather-and-compute kernel can be bound by and names as `bound`
+the largest of those whose peak the guide states (vector-instruction issue; the vector L1's request rate against a self-measured peak is
+carried for the record only -- round 4's probes showed the step does not wait for it), each with the source of its peak (`peak_source`: "guide" = /opt/skills/guides/MI355X_MICROARCH.md, "probe" = measured by tools/probes/), with the
 kernel's busy time measured live (union of the per-launch hipEvent intervals on the launch streams, median repetition) and the
 per-frame counter totals taken from the rocprofv3 --pmc passes of THIS command committed under profiles/ (tools/pmc_bench.sh).  The
 SURVEY 8d algorithmic byte rate is reported next to it, not as a fraction of a roof it does not touch: the scene is cache resident.
@@ -536,7 +536,11 @@ def main():
                 pmc_info["builder_kernel_busy_ms_per_frame"] = bms
             lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
             traffic = int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 * frames_per_launch)
-            bound = max(fractions, key=fractions.get)
+            # the bound is named among the resources whose peak the guide states.  `l1_gather_requests` stays in `fractions` for the record, against a
+            # self-measured peak (a pure 64-byte gather) -- but round 4's probes of the production kernel showed it is not what the step waits for: 20 %
+            # fewer requests per step bought nothing, every added vector / scalar instruction costs 0.1-0.25 % (profiles/r04_p1_step_sensitivity_probe.txt,
+            # r04_p2_vmem_cost_probes.txt, r04_g1_fetch_pieces_ab.txt).
+            bound = max((k for k in fractions if k != "l1_gather_requests"), key=fractions.get)
             roof = {"l1_gather_requests": ("l1", c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / s / 1e9, L1_GATHER_PEAK_GREQ, "Greq/s"),
                     "valu_issue": ("valu", c["SQ_INSTS_VALU"] / s / 1e9, VALU_PEAK_GINST, "Ginst/s"),
                     "l2_bandwidth": ("l2", (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE / s / 1e9, L2_PEAK_GBS, "GB/s"),
@@ -550,7 +554,7 @@ def main():
             "kernel_busy_ms": round(busy, 4), "kernel_busy_ms_per_frame": round(busy_per_frame, 5), "launches": int(len(k_ms)),
             "kernel_avg_launch_ms": round(float(np.mean(k_ms)), 4) if len(k_ms) else None, "frames_per_launch": frames_per_launch,
             "fractions": {k: round(v, 5) for k, v in fractions.items()},
-            "peak_source": {"l1_gather_requests": "probe (tools/probes/gather64.hip, profiles/r03_gather64_probe.txt: 871 G requests/s)", "valu_issue": "guide (SIMD-32: 2 cycles per wave64 instruction, 1,024 SIMDs, 2.4 GHz)",
+            "peak_source": {"l1_gather_requests": "probe (tools/probes/gather64.hip, profiles/r03_gather64_probe.txt: 871 G requests/s); informational -- not a candidate for `bound` (profiles/r04_g1_fetch_pieces_ab.txt)", "valu_issue": "guide (SIMD-32: 2 cycles per wave64 instruction, 1,024 SIMDs, 2.4 GHz)",
                             "l2_bandwidth": "guide (34.5 TB/s)", "hbm_fabric": "guide (8 TB/s)"},
             "fractions_over_builder_time": {k: round(v, 5) for k, v in fractions_builder.items()},
             "lane_utilisation": None if lane_util is None else round(lane_util, 4),
@@ -558,7 +562,7 @@ def main():
             "definition": "frac = (per-frame counter total of the timed launches, rocprofv3 --pmc of this command, profiles/) / (kernel busy time per frame, hipEvents of this run) / peak; "
                           "valu_issue: SQ_INSTS_VALU x 2 cycles over 1024 SIMDs x 2.4 GHz; l2_bandwidth: (TCC_HIT+TCC_MISS) x 128 B over 34.5 TB/s; "
                           "hbm_fabric: (FETCH_SIZE+WRITE_SIZE) x 1024 over 8 TB/s (FETCH_SIZE includes Infinity-Cache hits); l1_gather_requests: TCP_TOTAL_CACHE_ACCESSES over the "
-                          "request rate a pure 64-byte-record gather sustains (871 G/s, tools/probes/gather64.hip); bound = the largest; fractions_over_builder_time = the same "
+                          "request rate a pure 64-byte-record gather sustains (871 G/s, tools/probes/gather64.hip; informational); bound = the largest of the fractions whose peak the guide states; fractions_over_builder_time = the same "
                           "counters over the kernel time of the session the counters were taken in (another box: the two sets differ by the boxes' speed difference)",
             "algorithmic": {"GBps": round(algorithmic_gbs, 2), "bytes_per_frame": int(my_bytes), "bytes_per_frame_min_max": [int(min(frame_bytes)), int(max(frame_bytes))],
                             "over_hbm_peak": round(algorithmic_gbs / HBM_PEAK_GBS, 4),

@@ -363,6 +363,45 @@ def test_quad_mode_drain_bit_exact(rt, gpu_ctx, orc):
     gpu_ctx.debug_set_tune("QUAD")
 
 
+def test_forked_shadow_rays_bit_exact(rt, gpu_ctx, orc):
+    """Quad mode hands the shadow ray of a path that goes on to an idle quad of the wavefront and starts the next bounce at once
+    (pt_megakernel_loop.inc): the path's radiance terms are still added in bounce order (a path waits for its shadow ray's result at its
+    next event that adds one), so image and counters are those of the run without it and of the oracle -- and shadow rays ARE handed
+    over, found waiting for, and sometimes have no idle quad (the instrumented launch counts all three)."""
+    import ctypes as C
+    tris = rt.procedural_scene(0, 60000)
+    gpu_ctx.set_triangles(tris)
+    gpu_ctx.build_bvh()
+    kw = dict(mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, seed=5)
+    dbg = np.zeros(24, np.uint64)
+    res = {}
+    for fork in (0, 1):
+        gpu_ctx.debug_set_tune("FORK", fork)
+        gpu_ctx.render(gpu_ctx.make_params(640, 360, stats=True, **kw))
+        res[fork] = (gpu_ctx.read_radiance().copy(), gpu_ctx.stats())
+        rt.lib.pt_debug_counters(gpu_ctx.h, dbg.ctypes.data_as(C.c_void_p))
+        if fork:
+            assert dbg[19] > 0 and dbg[21] > 0, (dbg[19], dbg[20], dbg[21])      # handed over / paths that waited for theirs
+        else:
+            assert dbg[19] == 0 and dbg[21] == 0
+        gpu_ctx.render(gpu_ctx.make_params(640, 360, **kw))                     # the production kernel
+        assert same_bits(gpu_ctx.read_radiance(), res[fork][0]), fork
+    assert same_bits(res[0][0], res[1][0])
+    for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples", "max_stack", "stack_drops"):
+        assert res[0][1][k] == res[1][1][k], (k, res[0][1][k], res[1][1][k])
+    # against the oracle on a frame it finishes in seconds
+    bvh4 = gpu_ctx.read_bvh4()
+    cam, quat = CAMS[0]
+    gpu_ctx.render(gpu_ctx.make_params(160, 96, cam, quat, stats=True, **kw))
+    got = gpu_ctx.read_radiance().copy(); st = gpu_ctx.stats()
+    want, _, ost = orc.render(orc.make_params(160, 96, tris.size // 9, cam, quat, mode=orc_mod.MODE_PATH, spp=4, max_bounces=8, seed=5), tris, bvh4)
+    assert same_bits(got, want)
+    for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples"):
+        assert st[k] == ost[k], k
+    # quads from the first ray on (every shadow ray of a continuing path can be handed over) is an A/B build, not a knob: covered by tools/kvariants.sh
+    gpu_ctx.debug_set_tune("FORK")
+
+
 def test_batched_launch_equals_frame_by_frame(rt, gpu_ctx):
     """pt_set_batch: several frames traced by one persistent launch give exactly the per-frame results
     (each into the output target that was current at submission), including an accumulating sequence."""
