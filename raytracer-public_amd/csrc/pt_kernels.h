@@ -26,8 +26,11 @@
 #ifndef PT_QUAD
 #define PT_QUAD 1                  // 1: a wavefront with nothing left to start and at most PT_QUAD_LIVE paths goes on with one ray per quad of lanes (pt_megakernel.hip); 0: never; 2: quads from the first ray on (A/B builds)
 #endif
+#ifndef PT_FORK_LANES
+#define PT_FORK_LANES 1            // 1: shadow rays are also handed to idle LANES once a wavefront has nothing left to start (fork_shadow >= 2); 0: only to idle quads in quad mode
+#endif
 #ifndef PT_FORK_SHADOW
-#define PT_FORK_SHADOW 1          // quad mode: a path hands its shadow ray to an idle quad of its wavefront and goes on with the next bounce at once (pt_megakernel.hip)
+#define PT_FORK_SHADOW 2          // quad mode: a path hands its shadow ray to an idle quad of its wavefront and goes on with the next bounce at once (pt_megakernel.hip)
 #endif
 #ifndef PT_QUAD_LIVE
 #define PT_QUAD_LIVE 16            // paths a wavefront may hold when it re-seats them (16 quads per wavefront)

@@ -58,7 +58,7 @@ def main():
             # the drain's quad mode at its default and at odd thresholds (paths a wavefront may hold when it re-seats them; 0 = never)
             quad = int(rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 16, 9, 4, 1, 0]))
             ctx.debug_set_tune("QUAD", quad)
-            fork = int(rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 1, 0]))       # forked shadow rays in quad mode: default (on), on, off
+            fork = int(rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 2, 1, 0]))       # forked shadow rays: default (idle lanes and quads), the same, idle quads only, off
             ctx.debug_set_tune("FORK", fork)
             cfg = dict(kind=kind, n=n, w=w, h=h, spp=spp, bounces=bounces, nf=nf, accumulate=accumulate, count=count, batch=batch, seed=sd, quad=quad, fork=fork)
             kw = dict(mode=rt.PT_MODE_PATH, spp=spp, max_bounces=bounces, seed=sd)
