@@ -1,5 +1,5 @@
 #!/bin/bash
-# Static look at what the compiler made of trace_paths_kernel<false>: per loop depth of the two instances of the launch loop (one ray
+# Static look at what the compiler made of trace_paths_kernel<false>: per loop depth of the three instances of the launch loop (one ray
 # per lane / one ray per quad) the instruction count, vector instructions, register copies (v_mov_b32), idle issue slots (s_nop),
 # scratch accesses and SGPR-spill lane moves.  Round 4 found 2-3 % of a dense frame in things only this shows: ~220 register copies per
 # pass of the outer loop after an innocent-looking early exit, an `s_nop` behind every one-instruction asm statement, uniform flags spilled
