@@ -26,9 +26,6 @@
 #ifndef PT_QUAD
 #define PT_QUAD 1                  // 1: a wavefront with nothing left to start and at most PT_QUAD_LIVE paths goes on with one ray per quad of lanes (pt_megakernel.hip); 0: never; 2: quads from the first ray on (A/B builds)
 #endif
-#ifndef PT_TAIL_SHADE_SHIFT
-#define PT_TAIL_SHADE_SHIFT 2      // once a wavefront has nothing left to start, a shade pass is due when 1 / 2^this of its live lanes wait for one
-#endif
 #ifndef PT_FORK_LANES
 #define PT_FORK_LANES 1            // 1: shadow rays are also handed to idle LANES once a wavefront has nothing left to start (fork_shadow >= 2); 0: only to idle quads in quad mode
 #endif
