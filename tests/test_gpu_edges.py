@@ -191,24 +191,25 @@ def test_full_size_c5_4k_accumulate_smoke(rt, gpu_ctx_full):
     assert ms > 0
 
 
-@pytest.mark.parametrize("steps,fixed_batch", [(40, None), (23, None), (23, "8")])
-def test_bench_two_ranks_gloo_rehearsal_verifies_gathered_frame(steps, fixed_batch):
+@pytest.mark.parametrize("gpus,steps,fixed_batch", [(2, 40, None), (2, 23, None), (2, 23, "8"), (4, 20, None)])
+def test_bench_two_ranks_gloo_rehearsal_verifies_gathered_frame(gpus, steps, fixed_batch):
     """bench.py's N > 1 path end to end on the one-GPU box, started the way the driver starts it (`python bench.py --gpus 2`, no
     launcher): bench.py spawns its two ranks itself, they share cuda:0, the gather is staged through gloo
     (PT_BENCH_BACKEND=gloo), rank 0 de-interleaves every launch with one call and the last timed frame is checked against the CPU oracle.
     40 steps = four launches of 10 = full batches; 23 steps = 6, 6, 6, 5 with a 1 / 1 / 1 warm-up: launches SHORTER than the batch, so
-    pt_flush and a gather of fewer frames than the buffers hold are on the path; PT_BENCH_BATCH=8 = fixed batches 8, 8, 7."""
+    pt_flush and a gather of fewer frames than the buffers hold are on the path; PT_BENCH_BATCH=8 = fixed batches 8, 8, 7.  The last case
+    is the driver's command shape (20 steps: 5, 5, 5, 5) with FOUR ranks on the one GPU (within the box's limit of six GPU processes)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "PT_BENCH_BATCH", "PT_BENCH_SCHEDULE")}
     env.update(PT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     if fixed_batch:
         env["PT_BENCH_BATCH"] = fixed_batch
-    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "3",
+    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", str(steps), "--warmup", "3" if gpus == 2 else "5",
                                    "--width", "640", "--height", "360"], env=env, cwd=root, text=True, stderr=subprocess.STDOUT, timeout=600)
     line = [l for l in out.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["verified"] is True and res["value"] > 0 and res["scaling"] == "strong"
+    assert res["n_gpus"] == gpus and res["verified"] is True and res["value"] > 0 and res["scaling"] == "strong"
 
 
 def test_bench_single_gpu_contract_line():
