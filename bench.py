@@ -28,6 +28,9 @@ carried for the record only -- round 4's probes showed the step does not wait fo
 kernel's busy time measured live (union of the per-launch hipEvent intervals on the launch streams, median repetition) and the
 per-frame counter totals taken from the rocprofv3 --pmc passes of THIS command committed under profiles/ (tools/pmc_bench.sh).  The
 SURVEY 8d algorithmic byte rate is reported next to it, not as a fraction of a roof it does not touch: the scene is cache resident.
+`sustained` (N = 1): after the timed region the GPU renders for about 1.5 s in 32-frame launches -- the driver's 20 steps are 15 ms of GPU time,
+too short for any outside observer (a utilisation sampler) to see -- and the last of those frames, the one verified against the oracle, must come
+out bit-identical; its rate is reported next to `value`, never instead of it.
 `configs` adds the whole-frame rate of C4 (sponza-class interior: no empty space, every camera ray hits) and rays / node tests per
 second for both, so the figure that does not lean on empty space travels with the line.
 """
@@ -221,6 +224,8 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--verify", action="store_true", help="kept for compatibility: the check against the oracle always runs")
     ap.add_argument("--no-reference-shape", action="store_true", help="skip the one-render()-per-frame figures")
+    ap.add_argument("--sustained-seconds", type=float, default=1.5, help="N = 1: after the timed region, render for about this long in 32-frame launches and compare the "
+                                                                          "last frame with the verified one, bit for bit (0 = skip)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -453,6 +458,38 @@ def main():
                      "note": "pt_set_batch(1): one pt_render per frame as PathTracer.render() is called (src/main.js:70-74); pipelined = no host wait between frames, "
                              "solo = pt_synchronize after every frame; `value` above uses pt_set_batch, an extension the reference API does not have"}
 
+    # ---- sustained: a second or two of back-to-back 32-frame launches (the driver's 20 steps are 15 ms of GPU time: too short for any outside
+    #      observer -- a utilisation sampler, a power reading -- to see), ending on the frame that was verified above: it must come out bit-identical
+    sustained = None
+    if world == 1 and args.sustained_seconds > 0 and rank == 0:
+        ctx.set_output_buffer(0, 0)
+        ctx.set_batch(32)
+        ps = params(whole=True)
+        with torch.cuda.stream(stream):
+            for j in range(32):                  # one untimed launch: the frame slots are re-sized for 32-frame launches here
+                ps.frame = j % args.steps; ctx.render(ps)
+            launch_log.append(("sustained warmup", 32)); ctx.synchronize()
+        n_sus, t1 = 0, time.perf_counter()
+        with torch.cuda.stream(stream):
+            while True:
+                for j in range(32):
+                    ps.frame = args.steps - 1 if j == 31 else (n_sus + j) % args.steps      # the timed frames over and over; every launch ends on the verified one
+                    ctx.render(ps)
+                launch_log.append(("sustained", 32)); n_sus += 32
+                if n_sus % 256 == 0:
+                    ctx.synchronize()
+                    if time.perf_counter() - t1 >= args.sustained_seconds: break
+            ctx.synchronize()
+            dt = time.perf_counter() - t1
+            again = ctx.read_radiance().reshape(height, width, 4)
+        same = bool(np.array_equal(np.ascontiguousarray(again[::VERIFY_STEP, ::VERIFY_STEP]).view(np.uint32), np.ascontiguousarray(got[::VERIFY_STEP, ::VERIFY_STEP]).view(np.uint32)))
+        sustained = {"frames": n_sus, "seconds": round(dt, 3), "ms_per_frame": round(dt / n_sus * 1e3, 4), "msamples": round(width * height * SPP * n_sus / dt / 1e6, 1),
+                     "last_frame_identical_to_verified": same}
+        ctx.set_batch(1)
+        if not same:
+            print("bench.py: the verified frame came out differently at the end of the sustained run", file=sys.stderr, flush=True)
+            ctx.close(); sys.exit(3)
+
     # ---- the other single-GPU configuration: C4, a sponza-class interior (every camera ray hits, long paths: no empty space to lean on) --------
     configs = None
     if world == 1 and not args.no_configs and (width, height) == (WIDTH, HEIGHT):
@@ -586,6 +623,7 @@ def main():
                                     % (world, str(rect), pstride, stride)) if sharded else "single GPU, whole frame"},
             "roofline": roofline,
             "reference_call_shape": ref_shape,
+            "sustained": sustained,
             "configs": configs,
         }
         if world == 1 and not args.no_cpu_baseline and (width, height) == (WIDTH, HEIGHT):

@@ -15,9 +15,9 @@ i=0
 for CNT in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "TD_TD_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
-  timeout -k 10 400 rocprofv3 --pmc $CNT --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py $ARGS --no-cpu-baseline --no-configs > $OUT/pass$i.log 2>&1 || echo "pass $i ($CNT) failed" >> $OUT/errors.txt
+  timeout -k 10 400 rocprofv3 --pmc $CNT --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py $ARGS --no-cpu-baseline --no-configs --sustained-seconds 0 > $OUT/pass$i.log 2>&1 || echo "pass $i ($CNT) failed" >> $OUT/errors.txt
   cp $OUT/launch_log.json $OUT/launch_log_pass$i.json 2>/dev/null
 done
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS --no-cpu-baseline --no-configs > $OUT/trace.log 2>&1 || echo "kernel-trace run failed" >> $OUT/errors.txt
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS --no-cpu-baseline --no-configs --sustained-seconds 0 > $OUT/trace.log 2>&1 || echo "kernel-trace run failed" >> $OUT/errors.txt
 cp $OUT/launch_log.json $OUT/launch_log_trace.json 2>/dev/null
 python3 $ROOT/tools/pmc_bench_reduce.py $OUT "python3 bench.py $ARGS"
