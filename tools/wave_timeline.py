@@ -62,4 +62,3 @@ print('longest path %d traversal steps, longest ray %d; paths >= 512 steps: %d, 
 print('paths >= 512 steps: %.1f %% of their traversal steps belong to shadow rays (%d of %d)' % (100.0 * dbg[17] / max(int(dbg[18]), 1), dbg[17], dbg[18]))
 print('quad mode: shadow rays handed to an idle quad %d, no idle quad %d, paths that waited for their shadow ray %d; shadow rays in all %d' % (dbg[19], dbg[20], dbg[21], st['rays_shadow']))
 print('after a wavefront had nothing left to start: %.1f %% of its (path x iteration) slots were paths waiting for their forked shadow ray (%d of %d)' % (100.0 * dbg[22] / max(int(dbg[23]), 1), dbg[22], dbg[23]))
-print('path hand-over: %d paths taken by wavefronts that had finished their own work' % int(dbg[7]))
