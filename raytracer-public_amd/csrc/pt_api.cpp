@@ -71,6 +71,8 @@ struct PtContext {
 
     // scene (host mirrors kept for rebuilds / readback of small metadata only)
     uint32_t num_tris = 0, num_nodes2 = 0, num_nodes4 = 0;
+    bool edges_small = false;        // every |edge component| of the uploaded triangles is below 2^20 (pt_set_triangles; see det_is_bounded)
+    DevBuf<uint32_t> d_edge_max;
     bool have_tris = false, have_bvh = false, have_bvh2 = false;
     bool bvh2_refit_pending = false;  // pt_build_bvh leaves the internal BVH2 bounds to the first pt_read_bvh2 (nothing on the render path reads them)
     pt::WideBvh wide_meta;           // root info; nodes vector emptied after upload
@@ -268,6 +270,20 @@ bool root_box_rect(const pt::WideBvh& w, const ptk::FrameParams& f, uint32_t wid
     return true;
 }
 
+// May the triangle test take 1 / det by the short reciprocal (pt_device.h::rcp_normal: bit-identical to the division for |det| < 2^64)?
+// det = e1 . (d x e2), so |det| <= |e1| |e2| |d|: with every edge component below 2^20 (|e1| |e2| < 3 * 2^40) it suffices that no ray direction is
+// longer than 2^20.  Shadow and bounce directions are unit vectors; a camera direction is a unit vector rotated by the frame's quaternion -- scaled
+// by |q|^2 when that is not of unit length (renderer.wgsl:66-72) -- so every frame's |q|^2 has to stay below 2^20 (a NaN fails the compare).
+bool det_is_bounded(const PtContext* ctx, const std::vector<ptk::FrameParams>& frames, uint32_t nf) {
+    if (!ctx->edges_small) return false;
+    for (uint32_t i = 0; i < nf; ++i) {
+        const float* q = frames[i].quat;
+        const double n2 = double(q[0]) * q[0] + double(q[1]) * q[1] + double(q[2]) * q[2] + double(q[3]) * q[3];
+        if (!(n2 < 1048576.0)) return false;
+    }
+    return true;
+}
+
 // Launch the queued frames as one persistent launch (trace on a side stream, resolve on the main stream).
 int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count) {
     if (!ctx->pending) return PT_OK;
@@ -373,6 +389,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     A.shade_threshold = PtTune::pick(ctx->tune.shade, PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD);
     A.quad_live = std::min(16u, PtTune::pick(ctx->tune.quad, PT_QUAD_LIVE));     // 16 quads per wavefront
     A.fork_shadow = PtTune::pick(ctx->tune.fork, PT_FORK_SHADOW);
+    A.rcp_short = det_is_bounded(ctx, ctx->pending_frames, nf) ? 1u : 0u;
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
     // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
     // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small
@@ -662,11 +679,16 @@ int pt_set_triangles(PtContext* ctx, const float* tris, uint32_t num_tris) {
     PT_HIP(ctx, ctx->d_tris9.ensure(size_t(num_tris) * 9));
     ctx->scene_tris = ~0u;                          // new triangles: nothing in the arena is worth keeping
     if (int rc = ensure_scene(ctx, num_tris, uint64_t(num_tris) + 16u)) return rc;
+    uint32_t edge_bits = 0u;
     if (num_tris) {
+        PT_HIP(ctx, ctx->d_edge_max.ensure(1));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_edge_max.ptr, 0, sizeof(uint32_t), ctx->stream));
         PT_HIP(ctx, hipMemcpyAsync(ctx->d_tris9.ptr, tris, size_t(num_tris) * 36, hipMemcpyHostToDevice, ctx->stream));
-        PT_HIP(ctx, ptk::launch_tri_records(ctx->d_tris9.ptr, num_tris, ctx->trirec(), ctx->stream));   // 64 B records, DESIGN.md section 5
+        PT_HIP(ctx, ptk::launch_tri_records(ctx->d_tris9.ptr, num_tris, ctx->trirec(), ctx->d_edge_max.ptr, ctx->stream));   // 64 B records, DESIGN.md section 5
+        PT_HIP(ctx, hipMemcpyAsync(&edge_bits, ctx->d_edge_max.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->edges_small = edge_bits < 0x49800000u;     // 2^20 as f32 bits (NaN and infinity lie above)
     ctx->num_tris = num_tris;
     ctx->have_tris = true;
     ctx->have_bvh = false; ctx->have_bvh2 = false; ctx->bvh2_refit_pending = false;

@@ -48,6 +48,18 @@ __device__ __forceinline__ F3 safe_inv(F3 d) {      // renderer.wgsl:74-80
               fabsf(d.z) > 1e-8f ? 1.0f / d.z : kInfT);
 }
 
+// 1.0f / d for 2^-64 <= |d| < 2^64, bit-identical to the compiler's IEEE division in 7 instructions instead of 11: for such a denominator (and the
+// numerator 1.0) the two v_div_scale of the compiler's sequence return their inputs unscaled, its v_div_fmas is a plain fma and v_div_fixup returns
+// the quotient -- what remains is v_rcp + 6 fma, written out here (the multiplication by the numerator is exact and dropped).
+// tools/probes/rcp_exact.hip compares the two over EVERY f32 bit pattern of that range.  The caller takes the division outside it:
+// RenderArgs::rcp_short says whether the host could bound the operand (pt_api.cpp::det_is_bounded).
+__device__ __forceinline__ float rcp_normal(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    const float q = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), r, q);
+}
+
 __device__ __forceinline__ F3 rotate_quat(F3 v, const float* q) {   // renderer.wgsl:66-72
     const F3 u = f3(q[0], q[1], q[2]); const float s = q[3];
     const F3 uv = cross3(u, v), uuv = cross3(u, uv);

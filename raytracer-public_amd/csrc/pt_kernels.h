@@ -62,6 +62,7 @@ struct RenderArgs {
     const uint4*  scene;        // the arena both arrays live in: triangle record t at byte 64 t, wide node i at byte node_off + 64 i;
                                 // child references are positions in it in 16-byte units (packed references, pt_host.h)
     uint32_t      node_off;
+    uint32_t      rcp_short;    // 1: every |det| of the triangle test is below 2^64 for this scene and these cameras (pt_api.cpp): 1 / det by pt_device.h::rcp_normal
     uint32_t      tri_gate;     // 4 * numTris (16-byte units) when the UBO's numTris is smaller than the uploaded triangle count (leaves past it are entered, not tested), else 0xFFFFFFFF
     // device scene, reference layouts (literal packet kernel, LBVH build, readback)
     const uint32_t* bvh4_ref;   // u32[1 + 8*M]   renderer.wgsl:91-111
@@ -138,7 +139,8 @@ struct BuildBuffers {
     uint32_t* host_word;                 // pinned host word for the per-level counts
 };
 size_t build_temp_bytes(uint32_t num_tris);
-hipError_t launch_tri_records(const float* tris9, uint32_t num_tris, float4* records, hipStream_t stream);
+// edge_max (optional, zeroed by the caller): receives the largest |edge component| of the triangles as f32 bits
+hipError_t launch_tri_records(const float* tris9, uint32_t num_tris, float4* records, uint32_t* edge_max, hipStream_t stream);
 hipError_t launch_morton_sort(const BuildBuffers& B, const float* tris9, uint32_t num_tris, hipStream_t stream);
 // synchronises the stream once per BVH4 level (the level sizes size the next launch); *num_nodes4 = M on return
 hipError_t collapse_on_device(const BuildBuffers& B, const uint32_t* bvh2, uint32_t num_tris, uint32_t* bvh4, uint32_t* num_nodes4, hipStream_t stream);
