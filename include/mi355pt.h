@@ -331,7 +331,7 @@ PT_API int  pt_group_read_tonemapped(PtGroup* group, int from_rgba8, uint8_t* ds
  * Exported for this repository's own tests and tools (tests/test_gpu_parity.py, tools/sweep.sh, tools/wave_timeline.py); a binding
  * for the reference has no use for them and they may change between builds of the library. */
 /* Override one launch heuristic of this context ("GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL",
- * "STATSBATCH", "QUAD", "FORK"); value 0xFFFFFFFF restores the measured default.  Launches the open batch first.  The same knobs are read
+ * "STATSBATCH", "QUAD", "FORK", "BOUNDED"); value 0xFFFFFFFF restores the measured default.  Launches the open batch first.  The same knobs are read
  * from PT_TUNE_<NAME> once, when a context is created. */
 PT_API int pt_debug_set_tune(PtContext* ctx, const char* name, uint32_t value);
 /* Raw counter block (24 words) of the last PT_FLAG_STATS launch: PtStats order in [0..6], then the instrumented megakernel's own

@@ -41,16 +41,16 @@ struct DevBuf {
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto,
-             slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto, fork = kAuto;
+             slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto, fork = kAuto, bounded = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}, {"FORK", &PtTune::fork}};
+            {"FILL", &PtTune::fill}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}, {"FORK", &PtTune::fork}, {"BOUNDED", &PtTune::bounded}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL", "STATSBATCH", "QUAD", "FORK"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL", "STATSBATCH", "QUAD", "FORK", "BOUNDED"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -71,7 +71,7 @@ struct PtContext {
 
     // scene (host mirrors kept for rebuilds / readback of small metadata only)
     uint32_t num_tris = 0, num_nodes2 = 0, num_nodes4 = 0;
-    bool edges_small = false;        // every |edge component| of the uploaded triangles is below 2^20 (pt_set_triangles; see det_is_bounded)
+    bool edges_small = false;        // every |edge component| of the uploaded triangles is below 2^20 (pt_set_triangles; see arith_is_bounded)
     DevBuf<uint32_t> d_edge_max;
     bool have_tris = false, have_bvh = false, have_bvh2 = false;
     bool bvh2_refit_pending = false;  // pt_build_bvh leaves the internal BVH2 bounds to the first pt_read_bvh2 (nothing on the render path reads them)
@@ -270,16 +270,25 @@ bool root_box_rect(const pt::WideBvh& w, const ptk::FrameParams& f, uint32_t wid
     return true;
 }
 
-// May the triangle test take 1 / det by the short reciprocal (pt_device.h::rcp_normal: bit-identical to the division for |det| < 2^64)?
-// det = e1 . (d x e2), so |det| <= |e1| |e2| |d|: with every edge component below 2^20 (|e1| |e2| < 3 * 2^40) it suffices that no ray direction is
-// longer than 2^20.  Shadow and bounce directions are unit vectors; a camera direction is a unit vector rotated by the frame's quaternion -- scaled
-// by |q|^2 when that is not of unit length (renderer.wgsl:66-72) -- so every frame's |q|^2 has to stay below 2^20 (a NaN fails the compare).
-bool det_is_bounded(const PtContext* ctx, const std::vector<ptk::FrameParams>& frames, uint32_t nf) {
+// May the launch use the short forms of the correctly rounded reciprocal and square root (pt_device.h::rcp_normal / sqrt_normal: bit-identical to the
+// IEEE operations for operands of magnitude 2^-64 ... 2^64, and for sqrt(0))?  Their operands, site by site:
+//   * 1 / det of the triangle test, det = e1 . (d x e2), so |det| <= |e1| |e2| |d|: every edge component is below 2^20 (edges_small: |e1| |e2| < 3 * 2^40) and
+//     no ray direction is longer than 2^20 -- shadow and bounce directions are unit vectors, a camera direction is a unit vector rotated by the frame's
+//     quaternion, scaled by |q|^2 when that is not of unit length (renderer.wgsl:66-72): every frame's |q|^2 has to stay below 2^20.  A det below
+//     the range fails the test's own |det| < 1e-7 and its quotient is never used;
+//   * the three reciprocals of a ray's direction: taken only for |component| > 1e-8 (safeInvDir), bounded above as just said;
+//   * normalize() of the camera-space direction (p.x * aspect, p.y, -focal) with |p| <= 1: its squared length lies in [focal^2, aspect^2 + 1 + focal^2],
+//     so focal and aspect have to be of ordinary magnitude (1e-6 ... 1e6 is asked here);
+//   * the sampling (cosine_dir, Russian roulette): sqrt of u1 and 1 - u1 in [0, 1] (multiples of 2^-24: zero or >= 2^-24), 1 / (1 + |n.z|), 1 / max(T) with
+//     max(T) >= 0.3 -- always inside.
+// A NaN fails every compare below.
+bool arith_is_bounded(const PtContext* ctx, const std::vector<ptk::FrameParams>& frames, uint32_t nf) {
     if (!ctx->edges_small) return false;
     for (uint32_t i = 0; i < nf; ++i) {
         const float* q = frames[i].quat;
         const double n2 = double(q[0]) * q[0] + double(q[1]) * q[1] + double(q[2]) * q[2] + double(q[3]) * q[3];
         if (!(n2 < 1048576.0)) return false;
+        if (!(frames[i].focal > 1e-6f && frames[i].focal < 1e6f && frames[i].aspect < 1e6f && frames[i].aspect > -1e6f)) return false;
     }
     return true;
 }
@@ -389,7 +398,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     A.shade_threshold = PtTune::pick(ctx->tune.shade, PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD);
     A.quad_live = std::min(16u, PtTune::pick(ctx->tune.quad, PT_QUAD_LIVE));     // 16 quads per wavefront
     A.fork_shadow = PtTune::pick(ctx->tune.fork, PT_FORK_SHADOW);
-    A.rcp_short = det_is_bounded(ctx, ctx->pending_frames, nf) ? 1u : 0u;
+    A.rcp_short = (PtTune::pick(ctx->tune.bounded, 1u) != 0u && arith_is_bounded(ctx, ctx->pending_frames, nf)) ? 1u : 0u;      // knob BOUNDED = 0: always the general forms (tests)
     // frame slot (instrumented launches always use slot 0 and are not overlapped)
     // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
     // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small

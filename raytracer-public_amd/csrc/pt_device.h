@@ -20,7 +20,32 @@ __device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y *
 __device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ F3 cross3(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-__device__ __forceinline__ F3 normalize3(F3 v) { const float inv = 1.0f / sqrtf(dot3(v, v)); return v * inv; }
+// ---- short forms of the correctly rounded reciprocal and square root --------------------------------------------------------
+// 1.0f / d for 2^-64 <= |d| < 2^64, bit-identical to the compiler's IEEE division in 7 instructions instead of 11: for such a denominator (and the
+// numerator 1.0) the two v_div_scale of the compiler's sequence return their inputs unscaled, its v_div_fmas is a plain fma and v_div_fixup returns
+// the quotient -- what remains is v_rcp + 6 fma, written out here (the multiplication by the numerator is exact and dropped).
+// sqrtf(x) for x == 0 or 2^-64 <= x < 2^64 in 9 instructions instead of 16: the compiler's sequence without its scaling of small operands and its
+// zero / infinity fix-up -- v_sqrt, then the neighbours one ulp down and up are tried against the exact residuals.
+// Both are correctly rounded, so they equal the oracle's IEEE operations bit for bit; tools/probes/rcp_exact.hip compares them with `1.0f / x` and
+// `sqrtf(x)` over EVERY f32 bit pattern of those ranges.  Outside them the general forms are used: the megakernel is compiled in two variants
+// (BOUNDED), and the host picks the short one only where it can bound every operand (pt_api.cpp::arith_is_bounded).
+__device__ __forceinline__ float rcp_normal(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    const float q = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), r, q);
+}
+__device__ __forceinline__ float sqrt_normal(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    s = (r_dn <= 0.0f) ? s_dn : s;
+    return (r_up > 0.0f) ? s_up : s;
+}
+template <bool B> __device__ __forceinline__ float rcp_f(float d) { if constexpr (B) return rcp_normal(d); else return 1.0f / d; }
+template <bool B> __device__ __forceinline__ float sqrt_f(float x) { if constexpr (B) return sqrt_normal(x); else return sqrtf(x); }
+
+template <bool B = false> __device__ __forceinline__ F3 normalize3(F3 v) { const float inv = rcp_f<B>(sqrt_f<B>(dot3(v, v))); return v * inv; }
 // WGSL min/max on non-NaN data (sign of zero never reaches a comparison result)
 // -> v_min_f32 / v_max_f32 / v_min3_f32 / v_max3_f32
 __device__ __forceinline__ float wmin(float a, float b) { return __builtin_fminf(a, b); }
@@ -42,22 +67,10 @@ constexpr int kStackMax = 64;           // renderer.wgsl:8
 
 struct Ray { F3 o, d, inv; };
 
-__device__ __forceinline__ F3 safe_inv(F3 d) {      // renderer.wgsl:74-80
-    return f3(fabsf(d.x) > 1e-8f ? 1.0f / d.x : kInfT,
-              fabsf(d.y) > 1e-8f ? 1.0f / d.y : kInfT,
-              fabsf(d.z) > 1e-8f ? 1.0f / d.z : kInfT);
-}
-
-// 1.0f / d for 2^-64 <= |d| < 2^64, bit-identical to the compiler's IEEE division in 7 instructions instead of 11: for such a denominator (and the
-// numerator 1.0) the two v_div_scale of the compiler's sequence return their inputs unscaled, its v_div_fmas is a plain fma and v_div_fixup returns
-// the quotient -- what remains is v_rcp + 6 fma, written out here (the multiplication by the numerator is exact and dropped).
-// tools/probes/rcp_exact.hip compares the two over EVERY f32 bit pattern of that range.  The caller takes the division outside it:
-// RenderArgs::rcp_short says whether the host could bound the operand (pt_api.cpp::det_is_bounded).
-__device__ __forceinline__ float rcp_normal(float d) {
-    float r = __builtin_amdgcn_rcpf(d);
-    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-    const float q = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-    return __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), r, q);
+template <bool B = false> __device__ __forceinline__ F3 safe_inv(F3 d) {      // renderer.wgsl:74-80
+    return f3(fabsf(d.x) > 1e-8f ? rcp_f<B>(d.x) : kInfT,
+              fabsf(d.y) > 1e-8f ? rcp_f<B>(d.y) : kInfT,
+              fabsf(d.z) > 1e-8f ? rcp_f<B>(d.z) : kInfT);
 }
 
 __device__ __forceinline__ F3 rotate_quat(F3 v, const float* q) {   // renderer.wgsl:66-72
@@ -78,13 +91,13 @@ __device__ __forceinline__ Ray primary_ray(const RenderArgs& A, float fx, float 
     return r;
 }
 
-__device__ __forceinline__ Ray primary_ray_fp(const RenderArgs& A, const FrameParams& fp, float fx, float fy) {   // renderer.wgsl:387-395
+template <bool B = false> __device__ __forceinline__ Ray primary_ray_fp(const RenderArgs& A, const FrameParams& fp, float fx, float fy) {   // renderer.wgsl:387-395
     const float uvx = fx / (float)A.width, uvy = fy / (float)A.height;
     const float px = __builtin_fmaf(uvx, 2.0f, -1.0f), py = __builtin_fmaf(uvy, 2.0f, -1.0f);
     Ray r;
-    r.d = rotate_quat(normalize3(f3(px * fp.aspect, py, -fp.focal)), fp.quat);
+    r.d = rotate_quat(normalize3<B>(f3(px * fp.aspect, py, -fp.focal)), fp.quat);
     r.o = f3(fp.cam[0], fp.cam[1], fp.cam[2]);
-    r.inv = safe_inv(r.d);
+    r.inv = safe_inv<B>(r.d);
     return r;
 }
 
@@ -164,12 +177,12 @@ __device__ __forceinline__ void sincos_2pi(float u, float& c, float& s) {
     c = (k == 0) ? cy : (k == 1) ? -sy : (k == 2) ? -cy : sy;
     s = (k == 0) ? sy : (k == 1) ? cy : (k == 2) ? -sy : -cy;
 }
-__device__ __forceinline__ F3 cosine_dir(F3 n, float u1, float u2) {
+template <bool B = false> __device__ __forceinline__ F3 cosine_dir(F3 n, float u1, float u2) {
     float c, s; sincos_2pi(u2, c, s);
-    const float r = sqrtf(u1);
-    const float lx = r * c, ly = r * s, lz = sqrtf(1.0f - u1);
+    const float r = sqrt_f<B>(u1);
+    const float lx = r * c, ly = r * s, lz = sqrt_f<B>(1.0f - u1);
     const float sign = copysignf(1.0f, n.z);
-    const float a = -1.0f / (sign + n.z);
+    const float a = B ? -rcp_normal(sign + n.z) : -1.0f / (sign + n.z);        // (the quotient's sign is exact: -(1 / x) and (-1) / x are the same bits)
     const float b = n.x * n.y * a;
     const F3 t = f3(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
     const F3 bt = f3(b, sign + n.y * n.y * a, -n.y);

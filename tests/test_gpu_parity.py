@@ -322,6 +322,41 @@ def test_sponza_class_interior_bit_exact(rt, orc, gpu_ctx):
     assert (ids != 0xFFFFFFFF).mean() > 0.9        # interior: nearly every camera ray hits
 
 
+def test_short_reciprocal_forms_bit_exact(rt, gpu_ctx, orc):
+    """The megakernel exists in two variants: one takes every reciprocal and square root by the compiler's IEEE sequences, the other by short
+    correctly rounded forms that are only valid for operands of ordinary magnitude (pt_device.h::rcp_normal / sqrt_normal; tools/probes/rcp_exact.hip
+    checks them over every f32 bit pattern of their range).  The host picks the short variant where it can bound the operands
+    (pt_api.cpp::arith_is_bounded).  Both are the oracle's image bit for bit, and a camera whose quaternion is far from unit length (ray directions
+    a million times too long) takes the general variant by itself."""
+    import ctypes as C
+    tris, bvh4 = _scene(rt, orc, gpu_ctx, "dragon")
+    w, h = 160, 96
+    cam, quat = CAMS[0]
+    dbg = np.zeros(24, np.uint64)
+    op = orc.make_params(w, h, tris.size // 9, cam, quat, mode=orc_mod.MODE_PATH, spp=3, max_bounces=5, seed=11, frame=2)
+    ref, _, ost = orc.render(op, tris, bvh4)
+    for knob, variant in ((None, 1), (0, 0)):
+        gpu_ctx.debug_set_tune("BOUNDED", knob)
+        gpu_ctx.render(gpu_ctx.make_params(w, h, cam, quat, mode=rt.PT_MODE_PATH, spp=3, max_bounces=5, seed=11, frame=2, stats=True))
+        img = gpu_ctx.read_radiance(); st = gpu_ctx.stats()
+        rt.lib.pt_debug_counters(gpu_ctx.h, dbg.ctypes.data_as(C.c_void_p))
+        assert int(dbg[7]) == variant, (knob, int(dbg[7]))
+        assert same_bits(img, ref), knob
+        for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples"):
+            assert st[k] == ost[k], (knob, k, st[k], ost[k])
+    gpu_ctx.debug_set_tune("BOUNDED")
+    cam, quat = CAMS[2]                                            # inside the closed mesh: whatever the directions become, they hit
+    big = tuple(1100.0 * c for c in quat)                         # |q|^2 = 1.21e6 >= 2^20: the rotation terms of renderer.wgsl:66-72 scaled by that much
+    op = orc.make_params(w, h, tris.size // 9, cam, big, mode=orc_mod.MODE_PATH, spp=2, max_bounces=3, seed=11, frame=2)
+    ref, _, ost = orc.render(op, tris, bvh4)
+    gpu_ctx.render(gpu_ctx.make_params(w, h, cam, big, mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=11, frame=2, stats=True))
+    img = gpu_ctx.read_radiance()
+    rt.lib.pt_debug_counters(gpu_ctx.h, dbg.ctypes.data_as(C.c_void_p))
+    assert int(dbg[7]) == 0                                        # the general variant, chosen by the host
+    assert same_bits(img, ref)
+    assert (img[..., 0] != np.float32(0.01)).any()                 # the frame is not empty
+
+
 def test_quad_mode_drain_bit_exact(rt, gpu_ctx, orc):
     """Quad mode (a wavefront that has nothing left to start and holds at most 16 paths re-seats them one per quad of lanes: one child
     box per lane, Moller-Trumbore over three lanes, four stack entries per pop round) changes how a ray is executed, not what it does:
