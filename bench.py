@@ -23,14 +23,18 @@ The timed region (exactly K steps between barriers + synchronisations, max over 
 SURVEY 8d asks for at least 3) after the warm-up; `value` / `ms_per_step` are the MEDIAN repetition, `ms_per_step_min_max` the spread.
 
 The JSON line's `roofline` carries the fractions of the four resources a gather-and-compute kernel can be bound by and names as `bound`
-the largest of those whose peak the guide states (vector-instruction issue; the vector L1's request rate against a self-measured peak is
-carried for the record only -- round 4's probes showed the step does not wait for it), each with the source of its peak (`peak_source`: "guide" = /opt/skills/guides/MI355X_MICROARCH.md, "probe" = measured by tools/probes/), with the
+the largest of them -- whatever it is; `bound_by_probe` next to it says which resource the kernel RESPONDS to (round 4's probe builds of the
+production step: it is the executed vector work, not the vector L1's request rate, whose fraction of a self-measured peak is the larger number;
+DESIGN.md section 7) -- each with the source of its peak (`peak_source`: "guide" = /opt/skills/guides/MI355X_MICROARCH.md, "probe" = measured by tools/probes/), with the
 kernel's busy time measured live (union of the per-launch hipEvent intervals on the launch streams, median repetition) and the
 per-frame counter totals taken from the rocprofv3 --pmc passes of THIS command committed under profiles/ (tools/pmc_bench.sh).  The
 SURVEY 8d algorithmic byte rate is reported next to it, not as a fraction of a roof it does not touch: the scene is cache resident.
-`sustained` (N = 1): after the timed region the GPU renders for about 1.5 s in 32-frame launches -- the driver's 20 steps are 15 ms of GPU time,
-too short for any outside observer (a utilisation sampler) to see -- and the last of those frames, the one verified against the oracle, must come
-out bit-identical; its rate is reported next to `value`, never instead of it.
+`sustained` (N = 1): after the timed region the GPU renders for about 11 s in 32-frame launches -- the driver's 20 steps are 15 ms of GPU time,
+too short for any outside observer to see, and a utilisation sampler with a 5 s period needs two periods to be sure to land inside -- and the last of
+those frames, the one verified against the oracle, must come out bit-identical; its rate is reported next to `value`, never instead of it.
+`reference_call_shape`: one render() per frame as src/main.js:70-74 calls it -- pipelined (64 and 128 frames without a host wait: the steady rate is
+their difference, `drain_ms` what the 64-frame run took beyond it) and awaited (wall time per frame next to the GPU time hipEvents measured around the
+frame's kernels, so host latency and kernel time can be told apart).
 `configs` adds the whole-frame rate of C4 (sponza-class interior: no empty space, every camera ray hits) and rays / node tests per
 second for both, so the figure that does not lean on empty space travels with the line.
 """
@@ -60,7 +64,7 @@ L2_PEAK_GBS, L2_LINE, HBM_PEAK_GBS = 34500.0, 128, 8000.0
 # the vector L1's request rate for this access pattern (every lane gathers its own 64-byte record with 4 x dwordx4): 217.7 G records/s x 4
 # requests, measured chip-wide by tools/probes/gather64.hip (profiles/r03_gather64_probe.txt, V0) -- 1.42 requests per cycle and CU
 L1_GATHER_PEAK_GREQ = 217.7 * 4
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_bench.json")
 KERNEL_SOURCES = ["pt_megakernel.hip", "pt_megakernel_loop.inc", "pt_device.h", "pt_kernels.h"]
 VERIFY_STEP = 4         # the timed frame is checked on every 4th pixel in x and y (1/16 of the frame, ~0.6 s of oracle time)
 SHARD_PIECES = 4        # launches a sharded run is cut into at least (tools/shard_schedule_sim.py)
@@ -224,7 +228,7 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--verify", action="store_true", help="kept for compatibility: the check against the oracle always runs")
     ap.add_argument("--no-reference-shape", action="store_true", help="skip the one-render()-per-frame figures")
-    ap.add_argument("--sustained-seconds", type=float, default=1.5, help="N = 1: after the timed region, render for about this long in 32-frame launches and compare the "
+    ap.add_argument("--sustained-seconds", type=float, default=11.0, help="N = 1: after the timed region, render for about this long in 32-frame launches and compare the "
                                                                           "last frame with the verified one, bit for bit (0 = skip)")
     args = ap.parse_args()
 
@@ -309,12 +313,16 @@ def main():
     # launch per frame, before the timed region
     my_stats = None
     frame_bytes = []
+    import ctypes as C
+    dbg = np.zeros(24, np.uint64)
+    rays_entering = 0                # rays that enter the root box at all (camera rays that miss it are most of C2's "rays")
     with torch.cuda.stream(stream):
         if sharded:
             ctx.set_compact_buffer(compact[0][0].data_ptr(), stride)
         for i in range(args.steps):
             ctx.render(params(i, stats=True))
             st = ctx.stats()
+            rt.lib.pt_debug_counters(ctx.h, dbg.ctypes.data_as(C.c_void_p)); rays_entering += int(dbg[7]) >> 1
             frame_bytes.append(algorithmic_bytes(st))
             my_stats = st if my_stats is None else {k: my_stats[k] + st[k] for k in st}
     my_bytes = float(sum(frame_bytes)) / max(len(frame_bytes), 1)       # mean per frame
@@ -438,25 +446,33 @@ def main():
     if world == 1 and not args.no_reference_shape:
         ctx.set_output_buffer(0, 0)
         ctx.set_batch(1)
-        n_ref = max(4, min(args.steps, 32))
+        n_ref, n_solo = 64, max(8, min(args.steps, 32))
         pr = params(whole=True)
         with torch.cuda.stream(stream):
-            for i in range(4):
+            for i in range(8):
                 pr.frame = 5000 + i; ctx.render(pr); launch_log.append(("reference-shape warmup", 1))
             ctx.synchronize()
-            t1 = time.perf_counter()
-            for i in range(n_ref):               # frames follow each other like requestAnimationFrame callbacks that do not wait
-                pr.frame = 6000 + i; ctx.render(pr); launch_log.append(("reference-shape pipelined", 1))
-            ctx.synchronize()
-            pipelined = (time.perf_counter() - t1) / n_ref
-            t1 = time.perf_counter()
-            for i in range(n_ref):               # `await render()` + read-back before the next frame
+            walls = []
+            for n in (n_ref, 2 * n_ref):         # frames follow each other like requestAnimationFrame callbacks that do not wait; the run ends with a wait
+                t1 = time.perf_counter()
+                for i in range(n):
+                    pr.frame = 6000 + i; ctx.render(pr); launch_log.append(("reference-shape pipelined", 1))
+                ctx.synchronize()
+                walls.append(time.perf_counter() - t1)
+            steady = (walls[1] - walls[0]) / n_ref                  # what a frame costs while frames keep coming
+            drain = walls[0] - n_ref * steady                       # what the last frames' drain adds to a run that ends
+            t1 = time.perf_counter(); gpu_ms = []
+            for i in range(n_solo):              # `await render()` + read-back before the next frame
                 pr.frame = 7000 + i; ctx.render(pr); ctx.synchronize(); launch_log.append(("reference-shape solo", 1))
-            solo = (time.perf_counter() - t1) / n_ref
-        ref_shape = {"frames": n_ref, "ms_per_frame_pipelined": round(pipelined * 1e3, 4), "msamples_pipelined": round(width * height * SPP / pipelined / 1e6, 1),
-                     "ms_per_frame_solo": round(solo * 1e3, 4), "msamples_solo": round(width * height * SPP / solo / 1e6, 1),
-                     "note": "pt_set_batch(1): one pt_render per frame as PathTracer.render() is called (src/main.js:70-74); pipelined = no host wait between frames, "
-                             "solo = pt_synchronize after every frame; `value` above uses pt_set_batch, an extension the reference API does not have"}
+                gpu_ms.append(ctx.last_render_ms())                 # hipEvents on the context's stream around this frame's kernels (trace on its side stream + resolve)
+            solo = (time.perf_counter() - t1) / n_solo
+        ref_shape = {"frames_pipelined": [n_ref, 2 * n_ref], "ms_per_frame_pipelined": round(steady * 1e3, 4), "msamples_pipelined": round(width * height * SPP / steady / 1e6, 1),
+                     "ms_per_frame_pipelined_64_with_drain": round(walls[0] / n_ref * 1e3, 4), "drain_ms": round(drain * 1e3, 4),
+                     "frames_solo": n_solo, "ms_per_frame_solo": round(solo * 1e3, 4), "msamples_solo": round(width * height * SPP / solo / 1e6, 1),
+                     "gpu_ms_per_frame_solo": round(float(np.median(gpu_ms)), 4), "host_ms_per_frame_solo": round(solo * 1e3 - float(np.median(gpu_ms)), 4),
+                     "note": "pt_set_batch(1): one pt_render per frame as PathTracer.render() is called (src/main.js:70-74); pipelined = no host wait between frames (steady rate = "
+                             "(128-frame run - 64-frame run) / 64, drain_ms = the 64-frame run beyond 64 x that), solo = pt_synchronize after every frame (gpu = hipEvents around the "
+                             "frame's kernels, host = the rest of the wall time); `value` above uses pt_set_batch, an extension the reference API does not have"}
 
     # ---- sustained: a second or two of back-to-back 32-frame launches (the driver's 20 steps are 15 ms of GPU time: too short for any outside
     #      observer -- a utilisation sampler, a power reading -- to see), ending on the frame that was verified above: it must come out bit-identical
@@ -493,12 +509,13 @@ def main():
     # ---- the other single-GPU configuration: C4, a sponza-class interior (every camera ray hits, long paths: no empty space to lean on) --------
     configs = None
     if world == 1 and not args.no_configs and (width, height) == (WIDTH, HEIGHT):
-        def rates(st, seconds_per_frame):
-            return {"rays_per_s": round((st["rays_closest"] + st["rays_shadow"]) / seconds_per_frame, 1), "node_tests_per_s": round(st["nodes_examined"] / seconds_per_frame, 1),
+        def rates(st, seconds_per_frame, entering):
+            return {"rays_per_s": round((st["rays_closest"] + st["rays_shadow"]) / seconds_per_frame, 1), "rays_entering_root_per_s": round(entering / seconds_per_frame, 1), "node_tests_per_s": round(st["nodes_examined"] / seconds_per_frame, 1),
                     "tri_tests_per_s": round(st["tris_tested"] / seconds_per_frame, 1)}
         c2_frame = {k: my_stats[k] / args.steps for k in my_stats}
         configs = {"C2": {"ms_per_frame": round(elapsed / args.steps * 1e3, 4), "msamples": round(width * height * SPP * args.steps / elapsed / 1e6, 1),
-                          "rays_per_frame": int(c2_frame["rays_closest"] + c2_frame["rays_shadow"]), **rates(c2_frame, elapsed / args.steps)}}
+                          "rays_per_frame": int(c2_frame["rays_closest"] + c2_frame["rays_shadow"]), "rays_entering_root_per_frame": int(rays_entering / args.steps),
+                          **rates(c2_frame, elapsed / args.steps, rays_entering / args.steps)}}
         c4 = rt.Context(device)
         try:
             c4_tris = rt.procedural_scene(rt.SCENE_SPONZA_CLASS, 262144, SCENE_SEED)
@@ -506,6 +523,7 @@ def main():
             cam4, quat4 = (0.55, -0.05, 0.05), (0.0, 0.6630, 0.0, 0.7486)
             q = c4.make_params(width, height, cam4, quat4, mode=rt.PT_MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED, stats=True)
             c4.render(q); st4 = c4.stats()
+            rt.lib.pt_debug_counters(c4.h, dbg.ctypes.data_as(C.c_void_p)); enter4 = int(dbg[7]) >> 1
             q = c4.make_params(width, height, cam4, quat4, mode=rt.PT_MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED)
             c4.set_batch(8)
             for i in range(8):
@@ -521,7 +539,7 @@ def main():
             t4 = sorted(times)[1]
             configs["C4"] = {"workload": "sponza-class procedural interior, 262,144 triangles, camera inside, %dx%d, %d spp, %d bounces, 8 frames per launch, median of 3 launches" % (width, height, SPP, BOUNCES),
                              "ms_per_frame": round(t4 * 1e3, 3), "msamples": round(width * height * SPP / t4 / 1e6, 1), "ms_per_frame_min_max": [round(min(times) * 1e3, 3), round(max(times) * 1e3, 3)],
-                             "rays_per_frame": int(st4["rays_closest"] + st4["rays_shadow"]), **rates(st4, t4),
+                             "rays_per_frame": int(st4["rays_closest"] + st4["rays_shadow"]), "rays_entering_root_per_frame": enter4, **rates(st4, t4, enter4),
                              "algorithmic_GBps": round(algorithmic_bytes(st4) / t4 / 1e9, 1)}
         finally:
             c4.close()
@@ -573,25 +591,31 @@ def main():
                 pmc_info["builder_kernel_busy_ms_per_frame"] = bms
             lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
             traffic = int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 * frames_per_launch)
-            # the bound is named among the resources whose peak the guide states.  `l1_gather_requests` stays in `fractions` for the record, against a
-            # self-measured peak (a pure 64-byte gather) -- but round 4's probes of the production kernel showed it is not what the step waits for: 20 %
-            # fewer requests per step bought nothing, every added vector / scalar instruction costs 0.1-0.25 % (profiles/r04_p1_step_sensitivity_probe.txt,
-            # r04_p2_vmem_cost_probes.txt, r04_g1_fetch_pieces_ab.txt).
-            bound = max((k for k in fractions if k != "l1_gather_requests"), key=fractions.get)
-            roof = {"l1_gather_requests": ("l1", c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / s / 1e9, L1_GATHER_PEAK_GREQ, "Greq/s"),
-                    "valu_issue": ("valu", c["SQ_INSTS_VALU"] / s / 1e9, VALU_PEAK_GINST, "Ginst/s"),
-                    "l2_bandwidth": ("l2", (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE / s / 1e9, L2_PEAK_GBS, "GB/s"),
-                    "hbm_fabric": ("hbm", (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / s / 1e9, HBM_PEAK_GBS, "GB/s")}[bound]
+            # `bound` = the largest fraction, whatever it is.  `bound_by_probe` (below) carries what probe builds of the production step showed the kernel
+            # responds to: 20 % fewer L1 requests per step bought nothing, every added vector / scalar instruction costs 0.1-0.25 %, and round 5's removal of
+            # ~12 vector instructions per step bought 4 % (profiles/r04_p1_step_sensitivity_probe.txt, r04_g1_fetch_pieces_ab.txt, r05_d1_dense_micro_ab.txt).
+            bound = max(fractions, key=fractions.get)
+            rooftab = {"l1_gather_requests": ("l1", c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / s / 1e9, L1_GATHER_PEAK_GREQ, "Greq/s"),
+                       "valu_issue": ("valu", c["SQ_INSTS_VALU"] / s / 1e9, VALU_PEAK_GINST, "Ginst/s"),
+                       "l2_bandwidth": ("l2", (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE / s / 1e9, L2_PEAK_GBS, "GB/s"),
+                       "hbm_fabric": ("hbm", (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / s / 1e9, HBM_PEAK_GBS, "GB/s")}
+            roof = rooftab[bound]
+            probe_roof = rooftab["valu_issue"]
         else:
             roof = ("unmeasured", None, None, None)
+            probe_roof = None
         roofline = {
             "bound": roof[0], "achieved": None if roof[1] is None else round(roof[1], 2), "peak": roof[2], "unit": roof[3],
             "frac": None if roof[1] is None else round(roof[1] / roof[2], 5), "traffic": traffic,
-            "kernel": "trace_paths_kernel<false> (persistent megakernel)",
+            "bound_by_probe": None if probe_roof is None else {
+                "bound": probe_roof[0], "achieved": round(probe_roof[1], 2), "peak": probe_roof[2], "unit": probe_roof[3], "frac": round(probe_roof[1] / probe_roof[2], 5),
+                "evidence": "probe builds of the production step, same-session A/Bs: profiles/r04_p1_step_sensitivity_probe.txt (each added instruction costs 0.1-0.25 %), "
+                            "r04_g1_fetch_pieces_ab.txt (20 % fewer L1 requests: 2.5-3.6 % SLOWER), r05_d1_dense_micro_ab.txt (fewer vector instructions per step: faster by as much)"},
+            "kernel": "trace_paths_kernel<false, true> (persistent megakernel; no counters, short reciprocal forms)",
             "kernel_busy_ms": round(busy, 4), "kernel_busy_ms_per_frame": round(busy_per_frame, 5), "launches": int(len(k_ms)),
             "kernel_avg_launch_ms": round(float(np.mean(k_ms)), 4) if len(k_ms) else None, "frames_per_launch": frames_per_launch,
             "fractions": {k: round(v, 5) for k, v in fractions.items()},
-            "peak_source": {"l1_gather_requests": "probe (tools/probes/gather64.hip, profiles/r03_gather64_probe.txt: 871 G requests/s); informational -- not a candidate for `bound` (profiles/r04_g1_fetch_pieces_ab.txt)", "valu_issue": "guide (SIMD-32: 2 cycles per wave64 instruction, 1,024 SIMDs, 2.4 GHz)",
+            "peak_source": {"l1_gather_requests": "probe (tools/probes/gather64.hip, profiles/r03_gather64_probe.txt: 871 G requests/s of a pure 64-byte gather)", "valu_issue": "guide (SIMD-32: 2 cycles per wave64 instruction, 1,024 SIMDs, 2.4 GHz)",
                             "l2_bandwidth": "guide (34.5 TB/s)", "hbm_fabric": "guide (8 TB/s)"},
             "fractions_over_builder_time": {k: round(v, 5) for k, v in fractions_builder.items()},
             "lane_utilisation": None if lane_util is None else round(lane_util, 4),
@@ -599,7 +623,7 @@ def main():
             "definition": "frac = (per-frame counter total of the timed launches, rocprofv3 --pmc of this command, profiles/) / (kernel busy time per frame, hipEvents of this run) / peak; "
                           "valu_issue: SQ_INSTS_VALU x 2 cycles over 1024 SIMDs x 2.4 GHz; l2_bandwidth: (TCC_HIT+TCC_MISS) x 128 B over 34.5 TB/s; "
                           "hbm_fabric: (FETCH_SIZE+WRITE_SIZE) x 1024 over 8 TB/s (FETCH_SIZE includes Infinity-Cache hits); l1_gather_requests: TCP_TOTAL_CACHE_ACCESSES over the "
-                          "request rate a pure 64-byte-record gather sustains (871 G/s, tools/probes/gather64.hip; informational); bound = the largest of the fractions whose peak the guide states; fractions_over_builder_time = the same "
+                          "request rate a pure 64-byte-record gather sustains (871 G/s, tools/probes/gather64.hip); bound = the largest fraction; bound_by_probe = the resource probe builds showed the step responds to; fractions_over_builder_time = the same "
                           "counters over the kernel time of the session the counters were taken in (another box: the two sets differ by the boxes' speed difference)",
             "algorithmic": {"GBps": round(algorithmic_gbs, 2), "bytes_per_frame": int(my_bytes), "bytes_per_frame_min_max": [int(min(frame_bytes)), int(max(frame_bytes))],
                             "over_hbm_peak": round(algorithmic_gbs / HBM_PEAK_GBS, 4),
