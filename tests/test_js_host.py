@@ -21,6 +21,30 @@ def test_addon_host_functions_match_reference_vectors():
     assert out.startswith("ok ")
 
 
+def test_esm_face_runs_the_integration_sequence():
+    """The reference's driver binds with ES-module imports (src/main.js:1-2).  libs/PathTracer.js and libs/Scene.js (ES modules by
+    libs/package.json; .mjs aliases next to them) are that face: the INTEGRATION.md section-1 sequence up to buildMortonAndSort /
+    collapseLBVH2ToBVH4 runs through them under Node, against the reference-produced golden vectors."""
+    out = subprocess.check_output([NODE, os.path.join(HERE, "js_esm_check.mjs"), os.path.join(HERE, "golden", "pathtracer_js_golden.json")], text=True)
+    assert out.startswith("ok ")
+    # the ESM driver starts with the reference's two import lines as written
+    head = open(os.path.join(ROOT, "raytracer-public_amd", "js", "main.mjs")).read()
+    assert 'import * as PT from "./libs/PathTracer.js";\nimport * as PTScene from "./libs/Scene.js";' in head
+
+
+@pytest.mark.gpu
+def test_esm_face_renders_on_the_gpu(tmp_path, orc):
+    """src/main.js's sequence through the ES-module imports up to render(): the frame equals the oracle's bit for bit."""
+    import orc as orc_mod
+    out = subprocess.check_output([NODE, os.path.join(HERE, "js_esm_render.mjs"), os.path.join(HERE, "golden", "steve.glb"), str(tmp_path)], text=True)
+    assert out.strip().splitlines()[-1] == "ok 72"
+    tris = np.fromfile(str(tmp_path / "tris.bin"), np.float32)
+    bvh4, _ = orc.collapse_bvh4(orc.build_lbvh2(tris), 72)
+    ref, _, _ = orc.render(orc.make_params(160, 96, 72, (0.3, 0.2, 2.5), (0, 0, 0, 1), mode=orc_mod.MODE_SINGLE, frame=3), tris, bvh4)
+    img = np.fromfile(str(tmp_path / "img.bin"), np.float32).reshape(96, 160, 4)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
 def test_scene_js_matches_three_gltfloader():
     # Scene.loadGLB / parseGLTF / normalizeMesh / getTrianglesFloat32 vs the numbers three's GLTFLoader +
     # the reference's Scene.js arithmetic produced for the reference's two bundled GLBs
