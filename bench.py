@@ -322,7 +322,7 @@ def main():
         for i in range(args.steps):
             ctx.render(params(i, stats=True))
             st = ctx.stats()
-            rt.lib.pt_debug_counters(ctx.h, dbg.ctypes.data_as(C.c_void_p)); rays_entering += int(dbg[7]) >> 1
+            rt.lib.pt_debug_counters(ctx.h, dbg.ctypes.data_as(C.c_void_p)); rays_entering += (int(dbg[7]) & ((1 << 63) - 1)) >> 1
             frame_bytes.append(algorithmic_bytes(st))
             my_stats = st if my_stats is None else {k: my_stats[k] + st[k] for k in st}
     my_bytes = float(sum(frame_bytes)) / max(len(frame_bytes), 1)       # mean per frame
@@ -523,7 +523,7 @@ def main():
             cam4, quat4 = (0.55, -0.05, 0.05), (0.0, 0.6630, 0.0, 0.7486)
             q = c4.make_params(width, height, cam4, quat4, mode=rt.PT_MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED, stats=True)
             c4.render(q); st4 = c4.stats()
-            rt.lib.pt_debug_counters(c4.h, dbg.ctypes.data_as(C.c_void_p)); enter4 = int(dbg[7]) >> 1
+            rt.lib.pt_debug_counters(c4.h, dbg.ctypes.data_as(C.c_void_p)); enter4 = (int(dbg[7]) & ((1 << 63) - 1)) >> 1
             q = c4.make_params(width, height, cam4, quat4, mode=rt.PT_MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED)
             c4.set_batch(8)
             for i in range(8):

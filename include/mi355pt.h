@@ -315,7 +315,9 @@ PT_API int  pt_group_set_triangles(PtGroup* group, const float* tris, uint32_t n
 PT_API int  pt_group_build_bvh(PtGroup* group);
 PT_API int  pt_group_set_bvh2(PtGroup* group, const uint32_t* bvh2, uint64_t words);
 PT_API int  pt_group_set_bvh4(PtGroup* group, const uint32_t* bvh4, uint64_t words);
-/* pt_set_batch for every member; the gather then moves one batch per collective */
+/* pt_set_batch for every member; the gather then moves one batch per collective.  A group delivers ONE image per batch: the batch's LAST frame
+ * (pt_group_read_* return it; the frames before it are traced -- an accumulating sequence sums them -- but not rebuilt on rank 0).  The frames of a
+ * batch may differ in camera: what travels is cut to the union of their traced tile rectangles (none at all when no frame can see the scene). */
 PT_API int  pt_group_set_batch(PtGroup* group, uint32_t frames_per_launch);
 /* One frame over all members (tile_rank / tile_count of `params` are ignored).  Asynchronous. */
 PT_API int  pt_group_render(PtGroup* group, const PtRenderParams* params);

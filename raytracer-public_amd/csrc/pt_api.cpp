@@ -901,6 +901,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     if (p->mode == PT_MODE_PATH && p->spp == 0) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: spp must be >= 1");
     const uint32_t count = p->tile_count ? p->tile_count : 1;
     if (p->tile_rank >= count) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: tile_rank >= tile_count");
+    if (count > 0xfffu) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: tile_count > 4095 (the share a running accumulation covers is remembered as 12 + 12 bits; pt_set_accum has the same limit)");
     const bool sharded = count > 1 || (p->flags & PT_FLAG_COMPACT) != 0;
     const bool stats = (p->flags & PT_FLAG_STATS) != 0;
 
@@ -1203,7 +1204,12 @@ int pt_set_accum(PtContext* ctx, const PtAccumInfo* info, const float* src) {
     const uint64_t need = compact ? uint64_t(pt::tile_count_of(info->width, info->height, info->tile_rank, count)) * 256ull : uint64_t(info->width) * info->height * 4ull;
     if (info->floats != need) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_accum: `floats` does not match the shape (whole frame: W*H*4; tile share: tiles*64*4)");
     DevBuf<float4>& acc = compact ? ctx->d_compact_accum : ctx->d_accum;
+    // every pixel's w is the number of samples summed into it (resolve_kernel divides by it) and it is the same for all: a dump whose `samples`
+    // disagrees with its own data (edited by hand, truncated) would give means and checkpoint metadata that contradict each other
+    if (src[3] != float(info->samples) || src[need - 1] != float(info->samples))
+        return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_accum: `samples` does not match the sample count stored in the data (w of the first / last pixel)");
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // nothing in flight still reads or writes the running sums
+    everything_delivered(ctx);
     PT_HIP(ctx, acc.ensure(size_t(need / 4u)));
     PT_HIP(ctx, hipMemcpyAsync(acc.ptr, src, need * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // the host array is not retained

@@ -16,6 +16,7 @@
 #include "pt_device.h"
 
 namespace ptk {
+static_assert(kBgPrimary == 0.01f, "renderer.wgsl:410: packed tile shares (pt_group, bench.py) rebuild pixels outside the traced rectangle from this constant in every render mode");
 
 struct Counters { uint32_t nodes, tris, drops, maxstack; };
 
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void render_rays_kernel(const RenderArgs A) {
         float t; uint32_t tri;
         n_closest = 1;
         const bool hit = trace_any<false, STATS, BRUTE>(A, r, t, tri, stk, cnt);
-        F3 col = f3(0.01f, 0.01f, 0.01f);
+        F3 col = f3(kBgPrimary, kBgPrimary, kBgPrimary);      // renderer.wgsl:410 -- the ONE camera-miss value of every mode (unpack_frames_kernel fills untraced tiles with it)
         if (hit) {                                           // shade(), renderer.wgsl:348-353
             const float ndotl = wmax(dot3(hit_normal<BRUTE>(A, tri, r, t), L), 0.0f);
             col = base * (0.15f + ndotl);
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void render_packet_kernel(const RenderArgs A) 
     if (in_image) {                                          // renderer.wgsl:401-412
         const F3 base = f3(0.9f, 0.7f, 0.3f);
         const F3 L = light_dir();
-        F3 col = f3(0.01f, 0.01f, 0.01f);
+        F3 col = f3(kBgPrimary, kBgPrimary, kBgPrimary);      // renderer.wgsl:410 -- the ONE camera-miss value of every mode (unpack_frames_kernel fills untraced tiles with it)
         if (btri != kInvalidRef) col = base * (0.15f + wmax(dot3(bn, L), 0.0f));
         A.out[out_index] = make_float4(col.x, col.y, col.z, 1.0f);
         if (A.tri_ids) A.tri_ids[out_index] = btri;

@@ -59,6 +59,33 @@ def test_group_of_members_on_one_gpu_equals_the_whole_frame(rt, orc, scene, memb
         g.close()
 
 
+def test_group_batch_with_changing_cameras_delivers_its_last_frame(rt, scene):
+    """The frames of one batch may differ in camera: the packed shares are cut to the UNION of the frames' traced tile rectangles, and the
+    batch delivers its last frame -- also when that frame (or every frame) cannot see the scene at all (an empty rectangle: nothing travels,
+    rank 0 fills the image with the camera-miss value)."""
+    from scenes import quat_yaw_pitch
+    front, side, away = ((0, 0, 2.5), (0, 0, 0, 1)), ((0.4, 0.3, 1.7), quat_yaw_pitch(0.2, -0.15)), ((0, 0, 2.5), quat_yaw_pitch(3.14159, 0.0))
+    w, h = 160, 96
+    kw = dict(mode=rt.PT_MODE_PATH, spp=2, max_bounces=3, seed=4)
+    g = rt.Group([0] * 3, rt.PT_GROUP_TRANSPORT_COPY)
+    one = rt.Context(0)
+    try:
+        g.set_triangles(scene); g.build_bvh()
+        one.set_triangles(scene); one.build_bvh()
+        g.set_batch(3)
+        for order in ((front, away, side), (front, side, away), (away, away, away), (side, front, front)):
+            for f, (cam, quat) in enumerate(order):
+                g.render(g.make_params(w, h, cam, quat, frame=f, **kw))
+            cam, quat = order[-1]
+            one.render(one.make_params(w, h, cam, quat, frame=2, **kw))
+            want = one.read_radiance()
+            assert same_bits(g.read_radiance(), want), order
+            if order[-1] is away:
+                assert (want[..., :3] == np.float32(0.01)).all()          # nothing in view: the camera-miss value everywhere
+    finally:
+        one.close(); g.close()
+
+
 def test_group_result_survives_a_change_of_batch_and_shape(rt, scene):
     """The last gathered frame lives in rank 0's own frame buffer, not in the group's batch buffers: pt_group_set_batch (which frees and
     re-sizes those) and a read-back afterwards deliver the frame that was rendered (it used to be read from freed memory)."""

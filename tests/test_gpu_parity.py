@@ -341,7 +341,7 @@ def test_short_reciprocal_forms_bit_exact(rt, gpu_ctx, orc):
         img = gpu_ctx.read_radiance(); st = gpu_ctx.stats()
         rt.lib.pt_debug_counters(gpu_ctx.h, dbg.ctypes.data_as(C.c_void_p))
         assert int(dbg[7]) & 1 == variant, (knob, int(dbg[7]))
-        assert 0 < int(dbg[7]) >> 1 <= st["rays_closest"] + st["rays_shadow"]      # rays that entered the root box
+        assert 0 < (int(dbg[7]) & ((1 << 63) - 1)) >> 1 <= st["rays_closest"] + st["rays_shadow"]      # rays that entered the root box
         assert same_bits(img, ref), knob
         for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples"):
             assert st[k] == ost[k], (knob, k, st[k], ost[k])
@@ -417,6 +417,7 @@ def test_forked_shadow_rays_bit_exact(rt, gpu_ctx, orc):
         res[fork] = (gpu_ctx.read_radiance().copy(), gpu_ctx.stats())
         rt.lib.pt_debug_counters(gpu_ctx.h, dbg.ctypes.data_as(C.c_void_p))
         res_forks[fork] = int(dbg[19])
+        assert int(dbg[7]) >> 63 == 0, fork                                      # no forked shadow ray was lost (the shade pass's own check)
         if fork:
             assert dbg[19] > 0 and dbg[21] > 0, (dbg[19], dbg[20], dbg[21])      # handed over / paths that waited for theirs
         else:
