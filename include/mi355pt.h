@@ -336,6 +336,10 @@ PT_API int  pt_group_read_tonemapped(PtGroup* group, int from_rgba8, uint8_t* ds
  * "STATSBATCH", "QUAD", "FORK", "BOUNDED"); value 0xFFFFFFFF restores the measured default.  Launches the open batch first.  The same knobs are read
  * from PT_TUNE_<NAME> once, when a context is created. */
 PT_API int pt_debug_set_tune(PtContext* ctx, const char* name, uint32_t value);
+/* The launch heuristics as a pure function of the launch's shape (no GPU, no context; the measured defaults): out[12] = workgroups, rows / columns of
+ * the queue's batch transposition, logical items, items per claim, items per XCD range (0: one queue), shade / fill thresholds, paths at which a
+ * wavefront goes on with one ray per quad, shadow-ray forking, frame slots in rotation, frame slots set up.  (tests/test_launch_plan.py) */
+PT_API int pt_debug_launch_plan(uint32_t num_cus, uint32_t frames, uint32_t tile_count, uint32_t launches_in_flight, uint32_t traced_batches, uint32_t batch_size, uint32_t out[12]);
 /* Raw counter block (24 words) of the last PT_FLAG_STATS launch: PtStats order in [0..6], then the instrumented megakernel's own
  * diagnostics (stack pushes by depth, longest path / ray in traversal steps, re-seated wavefronts, ...). */
 PT_API int pt_debug_counters(PtContext* ctx, unsigned long long* dst24);

@@ -73,7 +73,7 @@ EXPORTS = [
     "pt_group_create", "pt_group_destroy", "pt_group_last_error", "pt_group_size", "pt_group_context", "pt_group_set_triangles", "pt_group_build_bvh",
     "pt_group_set_bvh2", "pt_group_set_bvh4", "pt_group_set_batch", "pt_group_render", "pt_group_flush", "pt_group_synchronize", "pt_group_read_radiance",
     "pt_group_read_rgba8", "pt_group_read_tonemapped",
-    "pt_debug_set_tune", "pt_debug_counters", "pt_debug_wave_times",     # diagnostics section of the header
+    "pt_debug_set_tune", "pt_debug_counters", "pt_debug_wave_times", "pt_debug_launch_plan",     # diagnostics section of the header
 ]
 
 

@@ -293,133 +293,115 @@ bool arith_is_bounded(const PtContext* ctx, const std::vector<ptk::FrameParams>&
     return true;
 }
 
-// Launch the queued frames as one persistent launch (trace on a side stream, resolve on the main stream).
-int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count) {
-    if (!ctx->pending) return PT_OK;
-    ptk::RenderArgs A = ctx->pendingA;
-    const uint32_t nf = ctx->pending;
-    ctx->pending = 0;
-    const bool ring = ctx->ring_used + 2 <= ctx->ring.size();
-    hipEvent_t e0 = ring ? ctx->ring[ctx->ring_used] : ctx->ev_start, e1 = ring ? ctx->ring[ctx->ring_used + 1] : ctx->ev_stop;
-    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    uint32_t grid = ptk::megakernel_grid(cus);
-    // a tile-sharded frame is a fraction of the work: fewer, denser wavefronts (measured: 1/8 frame best at grid/4);
-    // a batch of nf such frames is nf times the work again
-    {
-        // A single whole frame: the grid shrinks with the launches already in flight (one render() per frame without host waits,
-        // the reference's call shape: six frame slots, five neighbours, a quarter of the grid each -- 1.21 -> 1.01 ms per frame;
-        // a lone frame keeps the whole grid: 2.9 ms, 3.8 ms on a quarter of it).  tools/pipe_sweep.sh
-        uint32_t in_flight = 0;
-        if (count < 2u && nf == 1u && !stats)
-        {
-            for (const auto& o : ctx->slots) if (o.side && o.used && hipEventQuery(o.done) == hipErrorNotReady) ++in_flight;
-            (void)hipGetLastError();              // hipErrorNotReady is an answer, not an error: do not leave it behind for the launch checks
-        }
-        uint32_t div = PtTune::pick(ctx->tune.grid_div, count >= 8u ? 4u : (count >= 2u ? 2u : std::min(4u, 1u + in_flight)));
+// ---- a launch of the queued frames, in three steps: PLAN (pure arithmetic: the launch heuristics), PREPARE (frame slot, buffers, the list of
+// traced tiles), LAUNCH (trace on the slot's side stream, resolve on the context's stream).
+
+// What the heuristics need to know about a launch ...
+struct PlanInput {
+    uint32_t num_cus;            // compute units of the device
+    uint32_t frames;             // frames of the launch
+    uint32_t tile_count;         // tile shares the frame is cut into (1: whole frames)
+    bool     sharded;            // compact (tile-major) output
+    bool     stats;              // instrumented launch: slot 0, never overlapped
+    uint32_t launches_in_flight; // earlier launches of this context that have not finished (only asked for single whole frames)
+    uint32_t traced_batches;     // (frame, traced tile, sample) batches of 64 pixel-samples in the launch
+    uint32_t batch_size;         // pt_set_batch of the context: what a FULL launch of the current setting carries
+};
+// ... and what they decide (measured defaults, each overridable through PtTune; sources: DESIGN.md section 5, tools/sweep.sh)
+struct LaunchPlan {
+    uint32_t grid;               // workgroups of the persistent kernel
+    uint32_t perm_rows, perm_cols, total_items, chunk_items, xcd_span;       // the queue's walk through the batches
+    uint32_t shade_threshold, fill_threshold, quad_live, fork_shadow;
+    int      slots, setup_slots; // frame slots launches of this size rotate through / slots to have allocated (a full batch's count as well)
+    const char* error;           // nullptr, or why the launch cannot be made
+};
+
+int slots_for(const PtTune& tune, uint32_t frames, uint32_t tile_count, bool sharded) {
+    // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs its tail covered by the
+    // next one (and each extra overlapped launch stretches every launch's own duration), small sharded launches need several in flight to fill
+    // the chip.  Measured: tools/sweep.sh SLOTS, tools/pipe_sweep.sh.
+    const uint32_t w8 = frames * 8u / (tile_count ? tile_count : 1u);      // eighths of a whole frame
+    const int n = int(PtTune::pick(tune.slots, w8 >= 256u ? 3u : (w8 >= 64u ? 4u : (w8 >= 16u ? PT_FRAME_SLOTS : (w8 >= 8u ? (sharded ? 4u : 6u) : (sharded ? 8u : PT_FRAME_SLOTS))))));
+    return n < 1 ? 1 : (n > PtContext::kMaxSlots ? PtContext::kMaxSlots : n);
+}
+
+LaunchPlan plan_launch(const PtTune& tune, const PlanInput& in) {
+    LaunchPlan P; std::memset(&P, 0, sizeof(P));
+    const uint32_t nf = in.frames, count = in.tile_count ? in.tile_count : 1u;
+    const int cus = in.num_cus > 0 ? int(in.num_cus) : 256;
+    P.grid = ptk::megakernel_grid(cus);
+    {   // A tile-sharded frame is a fraction of the work: fewer, denser wavefronts (measured: 1/8 frame best at grid/4); a batch of nf such frames is
+        // nf times the work again.  A single whole frame: the grid shrinks with the launches already in flight (one render() per frame without host
+        // waits, the reference's call shape: six frame slots, a quarter of the grid each -- 1.21 -> 1.01 ms per frame; a lone frame keeps the whole
+        // grid: 2.9 ms, 3.8 ms on a quarter of it).  tools/pipe_sweep.sh
+        uint32_t div = PtTune::pick(tune.grid_div, count >= 8u ? 4u : (count >= 2u ? 2u : std::min(4u, 1u + in.launches_in_flight)));
         if (nf > 1u) div = div > nf ? div / nf : 1u;
-        if (div > 1u) grid = (grid + div - 1u) / div;
+        if (div > 1u) P.grid = (P.grid + div - 1u) / div;
     }
-    const uint32_t grid_lanes = grid * ptk::megakernel_block();
-    A.num_frames = nf;
-    if (uint64_t(A.num_tiles) * A.spp * nf * 64ull > 0xFFFFFFFFull) {     // item and sample indices are 32-bit
-        ctx->pending = 0;
-        return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: more than 2^32 pixel-samples in one launch (lower spp, the resolution or the batch)");
+    const uint32_t grid_lanes = P.grid * ptk::megakernel_block();
+    // Rows of the batch transposition (the order in which the queue walks the (frame, tile, sample) batches).  Rows that are a multiple or a divisor
+    // of the frame count keep the frames of a launch aligned: all rows are at the same image position at the same time, so the frames share the BVH
+    // nodes they pull through L2.  Long launches take one row per frame (few places in flight = locality); short launches cut every frame into 128
+    // segments (fine interleave of object and background tiles = balance when each wavefront only sees a few chunks).  tools/sweep.sh ROWS
+    const uint32_t work8 = nf * 8u / count;
+    P.perm_rows = PtTune::pick(tune.rows, work8 >= 64u ? nf : (work8 >= 8u ? 128u * nf : 64u * nf));
+    if (P.perm_rows < 1u) P.perm_rows = 1u;
+    if (P.perm_rows > 4096u) P.perm_rows = 4096u;
+    P.perm_cols = (in.traced_batches + P.perm_rows - 1u) / P.perm_rows;
+    if (uint64_t(P.perm_cols) * P.perm_rows * 64ull > 0xFFFFFFFFull) { P.error = "pt_render: batch too large (more than 2^32 items per launch)"; return P; }
+    P.total_items = P.perm_cols * P.perm_rows * 64u;
+    // two batches per claim: what a wavefront still holds when the queue runs dry is what the launch ends on (512: 20-frame launches 16 % slower, lone
+    // frames 25 %; 64: one atomic per batch costs 5 % in long launches); whole batches of 64: the kernel generates camera rays a batch at a time
+    P.chunk_items = ((PtTune::pick(tune.chunk, 128u) + 63u) / 64u) * 64u;
+    if (P.chunk_items < 64u) P.chunk_items = 64u;
+    // every wavefront adds chunk_items to a 32-bit cursor once more after it has found the queue dry (once per XCD range with the XCD-aware queue): the
+    // cursor must not wrap, or items would be handed out twice and the launch would never end
+    if (uint64_t(P.total_items) + uint64_t(grid_lanes / 64u + 1u) * P.chunk_items > 0xFFFFFFFFull) {
+        P.error = "pt_render: launch too large for the 32-bit work-queue cursor (more than 2^32 - grid * chunk items; lower spp, the resolution or the batch)"; return P;
     }
-    A.batches_per_frame = A.num_tiles * A.spp;
-    A.num_sample_batches = A.batches_per_frame * nf;
-    // ---- which owned tiles are traced at all: the union over the launch's frames of the root box's screen rectangle
-    std::vector<uint32_t> traced;                 // owned-tile slots inside the rectangle (empty + cull == false: all of them)
-    bool cull = false; TileRect rect = {0, 0, 0, 0};
-    if (ctx->have_bvh && ctx->wide_meta.root_ref != pt::kInvalid && !ctx->wide_meta.root_degenerate && A.num_tris != 0u && ctx->tune.cull != 0u) {
-        cull = true;
-        for (uint32_t i = 0; i < nf && cull; ++i) {
-            TileRect r;
-            if (!root_box_rect(ctx->wide_meta, ctx->pending_frames[i], A.width, A.height, r)) { cull = false; break; }
-            if (i == 0) rect = r;
-            else { rect.tx0 = std::min(rect.tx0, r.tx0); rect.ty0 = std::min(rect.ty0, r.ty0); rect.tx1 = std::max(rect.tx1, r.tx1); rect.ty1 = std::max(rect.ty1, r.ty1); }
-        }
-        const uint32_t tiles_y = (A.height + pt::kTile - 1) / pt::kTile;
-        if (cull && rect.tx0 == 0u && rect.ty0 == 0u && rect.tx1 >= A.tiles_x && rect.ty1 >= tiles_y) cull = false;     // nothing to leave out
+    {   // XCD-aware queue for long launches: 8 ranges of the logical item order, one cursor per XCD (chunk aligned; 0 = one queue).  Measured (tools/sweep.sh
+        // XCD): 32-frame launches +2..3.5 %, HBM fetch traffic halved (L2 hit rate 85 -> 91 %); no gain at 8 frames of work, a loss for a single frame
+        const uint32_t per = (P.total_items + 7u) / 8u;
+        P.xcd_span = PtTune::pick(tune.xcd, work8 >= 64u ? 1u : 0u) ? ((per + P.chunk_items - 1u) / P.chunk_items) * P.chunk_items : 0u;
     }
-    A.num_trace_tiles = A.num_tiles;
-    if (cull) {
-        auto inside = [&](uint32_t tile) { const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x; return tx >= rect.tx0 && tx < rect.tx1 && ty >= rect.ty0 && ty < rect.ty1; };
-        if (sharded) { for (uint32_t sl = 0; sl < A.num_tiles; ++sl) if (inside(ctx->tiles_host[sl])) traced.push_back(sl); }
-        else { for (uint32_t ty = rect.ty0; ty < rect.ty1; ++ty) for (uint32_t tx = rect.tx0; tx < rect.tx1; ++tx) traced.push_back(ty * A.tiles_x + tx); }
-        A.num_trace_tiles = uint32_t(traced.size());
+    P.shade_threshold = PtTune::pick(tune.shade, PT_SHADE_THRESHOLD); P.fill_threshold = PtTune::pick(tune.fill, PT_FILL_THRESHOLD);
+    P.quad_live = std::min(16u, PtTune::pick(tune.quad, PT_QUAD_LIVE));     // 16 quads per wavefront
+    P.fork_shadow = PtTune::pick(tune.fork, PT_FORK_SHADOW);
+    P.slots = in.stats ? 1 : slots_for(tune, nf, count, in.sharded);
+    // slots are set up for what a FULL batch of the current setting rotates through as well: a partial launch (a warm-up, a flush before a read-back) must
+    // not leave the first full one to allocate and prime a slot
+    P.setup_slots = in.stats ? 1 : std::max(P.slots, slots_for(tune, std::max(nf, in.batch_size), count, in.sharded));
+    return P;
+}
+
+// Which owned tiles are traced at all: the union over the launch's frames of the root box's screen rectangle (root_box_rect).  Returns false for
+// "every owned tile"; otherwise `traced` lists the owned-tile slots inside `rect`.
+bool traced_tiles(const PtContext* ctx, const ptk::RenderArgs& A, uint32_t nf, bool sharded, TileRect& rect, std::vector<uint32_t>& traced) {
+    traced.clear(); rect = {0, 0, 0, 0};
+    if (!(ctx->have_bvh && ctx->wide_meta.root_ref != pt::kInvalid && !ctx->wide_meta.root_degenerate && A.num_tris != 0u && ctx->tune.cull != 0u)) return false;
+    for (uint32_t i = 0; i < nf; ++i) {
+        TileRect r;
+        if (!root_box_rect(ctx->wide_meta, ctx->pending_frames[i], A.width, A.height, r)) return false;
+        if (i == 0) rect = r;
+        else { rect.tx0 = std::min(rect.tx0, r.tx0); rect.ty0 = std::min(rect.ty0, r.ty0); rect.tx1 = std::max(rect.tx1, r.tx1); rect.ty1 = std::max(rect.ty1, r.ty1); }
     }
-    ctx->stats_culled = 0;
-    if (stats && cull) {                          // the oracle traces these rays too: one closest ray, one root record, one sample each
-        uint64_t px_all = 0, px_traced = 0;
-        auto tile_px = [&](uint32_t tile) { const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x; return uint64_t(std::min(8u, A.width - tx * 8u)) * std::min(8u, A.height - ty * 8u); };
-        for (uint32_t sl = 0; sl < A.num_tiles; ++sl) px_all += tile_px(sharded ? ctx->tiles_host[sl] : sl);
-        for (uint32_t sl : traced) px_traced += tile_px(sharded ? ctx->tiles_host[sl] : sl);
-        ctx->stats_culled = (px_all - px_traced) * A.spp * nf;
-    }
-    A.trace_bpf = A.num_trace_tiles * A.spp;
-    A.num_batches = A.trace_bpf * nf;
-    auto magic = [](uint32_t d) { return d > 1u ? uint32_t(0x100000000ull / d) : 0xFFFFFFFFu; };      // d == 1: mulhi gives n - 1 (n > 0), corrected in the kernel
-    A.trace_bpf_magic = magic(A.trace_bpf ? A.trace_bpf : 1u); A.spp_magic = magic(A.spp); A.tiles_x_magic = magic(A.tiles_x);
-    if (A.num_batches == 0u) {
-        // every owned tile is culled (or there is none): nothing to trace, the resolve pass delivers the primed miss values
-        A.trace_bpf = 1u; A.trace_bpf_magic = magic(1u);
-    }
-    // Rows of the batch transposition (the order in which the queue walks the (frame, tile, sample) batches).  Rows that are a
-    // multiple or a divisor of the frame count keep the frames of a launch aligned: all rows are at the same image position at
-    // the same time, so the frames share the BVH nodes they pull through L2.  Long launches take one row per frame (few places
-    // in flight = locality); short launches cut every frame into 128 segments (fine interleave of object and background tiles
-    // = balance when each wavefront only sees a few chunks).  Measured: tools/sweep.sh ROWS.
-    {
-        const uint32_t work8_r = nf * 8u / (count ? count : 1u);
-        A.perm_rows = PtTune::pick(ctx->tune.rows, work8_r >= 64u ? nf : (work8_r >= 8u ? 128u * nf : 64u * nf));
-    }
-    if (A.perm_rows < 1u) A.perm_rows = 1u;
-    if (A.perm_rows > 4096u) A.perm_rows = 4096u;
-    A.perm_rows_magic = A.perm_rows > 1u ? uint32_t(0x100000000ull / A.perm_rows) : 0xFFFFFFFFu;   // rows == 1: mulhi gives lb - 1 (lb > 0), corrected in the kernel
-    A.perm_cols = (A.num_batches + A.perm_rows - 1u) / A.perm_rows;
-    if (uint64_t(A.perm_cols) * A.perm_rows * 64ull > 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: batch too large (more than 2^32 items per launch)");
-    A.total_items = A.perm_cols * A.perm_rows * 64u;
-    A.chunk_items = PtTune::pick(ctx->tune.chunk, 128u);     // two batches per claim: what a wavefront still holds when the queue runs dry is what the launch ends on (512: 20-frame launches 16 % slower, lone frames 25 %; 64: one atomic per batch costs 5 % in long launches)
-    A.chunk_items = ((A.chunk_items + 63u) / 64u) * 64u;           // whole batches of 64: the kernel generates camera rays a batch at a time
-    if (A.chunk_items < 64u) A.chunk_items = 64u;
-    // every wavefront adds chunk_items to a 32-bit cursor once more after it has found the queue dry (once per XCD range with
-    // the XCD-aware queue): the cursor must not wrap, or items would be handed out twice and the launch would never end
-    if (uint64_t(A.total_items) + uint64_t(grid_lanes / 64u + 1u) * A.chunk_items > 0xFFFFFFFFull) {
-        ctx->pending = 0;
-        return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: launch too large for the 32-bit work-queue cursor (more than 2^32 - grid * chunk items; lower spp, the resolution or the batch)");
-    }
-    {   // XCD-aware queue for long launches: 8 ranges of the logical item order, one cursor per XCD (chunk aligned; 0 = one queue).
-        // Measured (tools/sweep.sh XCD): 32-frame launches +2..3.5 %, HBM fetch traffic halved (L2 hit rate 85 -> 91 %);
-        // no gain at 8 frames of work, a loss for a single frame (the ranges are not equally heavy).
-        const uint32_t per = (A.total_items + 7u) / 8u;
-        const uint32_t work8_q = nf * 8u / (count ? count : 1u);
-        A.xcd_span = PtTune::pick(ctx->tune.xcd, work8_q >= 64u ? 1u : 0u) ? ((per + A.chunk_items - 1u) / A.chunk_items) * A.chunk_items : 0u;
-    }
-    A.shade_threshold = PtTune::pick(ctx->tune.shade, PT_SHADE_THRESHOLD); A.fill_threshold = PtTune::pick(ctx->tune.fill, PT_FILL_THRESHOLD);
-    A.quad_live = std::min(16u, PtTune::pick(ctx->tune.quad, PT_QUAD_LIVE));     // 16 quads per wavefront
-    A.fork_shadow = PtTune::pick(ctx->tune.fork, PT_FORK_SHADOW);
-    A.rcp_short = (PtTune::pick(ctx->tune.bounded, 1u) != 0u && arith_is_bounded(ctx, ctx->pending_frames, nf)) ? 1u : 0u;      // knob BOUNDED = 0: always the general forms (tests)
-    // frame slot (instrumented launches always use slot 0 and are not overlapped)
-    // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs
-    // its tail covered by the next one (and each extra overlapped launch stretches every launch's own duration), small
-    // sharded launches need several in flight to fill the chip.  Measured: tools/sweep.sh SLOTS, tools/pipe_sweep.sh.
-    auto slots_for = [&](uint32_t frames) {
-        const uint32_t w8 = frames * 8u / (count ? count : 1u);      // eighths of a whole frame
-        int n = int(PtTune::pick(ctx->tune.slots, w8 >= 256u ? 3u : (w8 >= 64u ? 4u : (w8 >= 16u ? PT_FRAME_SLOTS : (w8 >= 8u ? (sharded ? 4u : 6u) : (sharded ? 8u : PT_FRAME_SLOTS))))));
-        return n < 1 ? 1 : (n > PtContext::kMaxSlots ? PtContext::kMaxSlots : n);
-    };
-    const int want_slots = slots_for(nf);
-    // slots are set up for what a FULL batch of the current setting rotates through as well: a partial launch (a warm-up, a
-    // flush before a read-back) must not leave the first full one to allocate and prime a slot
-    const int setup_slots = std::max(want_slots, slots_for(std::max(nf, ctx->batch_size)));
-    ctx->num_slots = want_slots;
-    // Every slot is sized for a full batch of the current setting (largest grid) and prefilled as a whole the first time
-    // it is needed; from then on the resolve passes keep the buffers primed, whatever prefix a later launch uses.
+    const uint32_t tiles_y = (A.height + pt::kTile - 1) / pt::kTile;
+    if (rect.tx0 == 0u && rect.ty0 == 0u && rect.tx1 >= A.tiles_x && rect.ty1 >= tiles_y) return false;     // nothing to leave out
+    auto inside = [&](uint32_t tile) { const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x; return tx >= rect.tx0 && tx < rect.tx1 && ty >= rect.ty0 && ty < rect.ty1; };
+    if (sharded) { for (uint32_t sl = 0; sl < A.num_tiles; ++sl) if (inside(ctx->tiles_host[sl])) traced.push_back(sl); }
+    else { for (uint32_t ty = rect.ty0; ty < rect.ty1; ++ty) for (uint32_t tx = rect.tx0; tx < rect.tx1; ++tx) traced.push_back(ty * A.tiles_x + tx); }
+    return true;
+}
+
+// Streams, events and buffers of the frame slots a launch of this plan may use: every slot is sized for a full batch of the current setting (largest
+// grid) and its control block zeroed the first time it is needed; from then on the resolve passes rewind it, whatever prefix a later launch uses.
+int prepare_slots(PtContext* ctx, const LaunchPlan& P, const ptk::RenderArgs& A, uint32_t nf, bool stats) {
     const size_t n_samples = size_t(A.num_sample_batches) * 64u;
     const size_t cap_samples = std::max(n_samples, size_t(A.batches_per_frame) * 64u * size_t(ctx->batch_size));
     if (cap_samples > 0xFFFFFFFFull) return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: batch too large (more than 2^32 samples per launch)");
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     const uint32_t full_lanes = ptk::megakernel_grid(cus) * ptk::megakernel_block();
-    for (int si = 0; si < (stats ? 1 : setup_slots); ++si) {
+    for (int si = 0; si < (stats ? 1 : P.setup_slots); ++si) {
         PtContext::FrameSlot& s = ctx->slots[si];
         if (!s.side) {
             PT_HIP(ctx, hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
@@ -437,53 +419,107 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
             s.primed_ptr = s.samples.ptr; s.primed_samples = cap_samples;
         }
     }
-    PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(want_slots))];
+    return PT_OK;
+}
+
+// The list of traced tiles of a launch into the slot's device array, through a pinned staging buffer of the slot; rebuilt only when the rectangle
+// (or the tile share) changes.  The copy itself is queued by the caller's launch step (on the slot's stream, behind what it still waits for).
+int stage_traced_tiles(PtContext* ctx, PtContext::FrameSlot& sl, const uint32_t key[8], const std::vector<uint32_t>& traced) {
+    if (sl.cull_valid && std::memcmp(key, sl.cull_key, 8 * sizeof(uint32_t)) == 0) return PT_OK;
+    if (!sl.trace_copied) PT_HIP(ctx, hipEventCreateWithFlags(&sl.trace_copied, hipEventDisableTiming));
+    else PT_HIP(ctx, hipEventSynchronize(sl.trace_copied));                   // the previous copy out of the staging buffer is done
+    if (sl.h_trace_cap < traced.size()) {
+        if (sl.h_trace) (void)hipHostFree(sl.h_trace);
+        sl.h_trace = nullptr; sl.h_trace_cap = 0;
+        PT_HIP(ctx, hipHostMalloc((void**)&sl.h_trace, std::max<size_t>(traced.size(), 1024) * sizeof(uint32_t), hipHostMallocDefault));
+        sl.h_trace_cap = std::max<size_t>(traced.size(), 1024);
+    }
+    PT_HIP(ctx, sl.trace_slots.ensure(std::max<size_t>(traced.size(), 1)));
+    if (!traced.empty()) std::memcpy(sl.h_trace, traced.data(), traced.size() * sizeof(uint32_t));
+    sl.cull_valid = false;
+    return PT_OK;
+}
+
+// Launch the queued frames as one persistent launch (trace on a side stream, resolve on the main stream).
+int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count) {
+    if (!ctx->pending) return PT_OK;
+    ptk::RenderArgs A = ctx->pendingA;
+    const uint32_t nf = ctx->pending;
+    ctx->pending = 0;
+    const bool ring = ctx->ring_used + 2 <= ctx->ring.size();
+    hipEvent_t e0 = ring ? ctx->ring[ctx->ring_used] : ctx->ev_start, e1 = ring ? ctx->ring[ctx->ring_used + 1] : ctx->ev_stop;
+    A.num_frames = nf;
+    if (uint64_t(A.num_tiles) * A.spp * nf * 64ull > 0xFFFFFFFFull)     // item and sample indices are 32-bit
+        return fail(ctx, PT_ERR_INVALID_ARG, "pt_render: more than 2^32 pixel-samples in one launch (lower spp, the resolution or the batch)");
+    A.batches_per_frame = A.num_tiles * A.spp;
+    A.num_sample_batches = A.batches_per_frame * nf;
+
+    // ---- plan ---------------------------------------------------------------------------------------------------------------
+    std::vector<uint32_t> traced;                 // owned-tile slots inside the rectangle (cull == false: all of them)
+    TileRect rect;
+    const bool cull = traced_tiles(ctx, A, nf, sharded, rect, traced);
+    A.num_trace_tiles = cull ? uint32_t(traced.size()) : A.num_tiles;
+    ctx->stats_culled = 0;
+    if (stats && cull) {                          // the oracle traces these rays too: one closest ray, one root record, one sample each
+        uint64_t px_all = 0, px_traced = 0;
+        auto tile_px = [&](uint32_t tile) { const uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x; return uint64_t(std::min(8u, A.width - tx * 8u)) * std::min(8u, A.height - ty * 8u); };
+        for (uint32_t sl = 0; sl < A.num_tiles; ++sl) px_all += tile_px(sharded ? ctx->tiles_host[sl] : sl);
+        for (uint32_t sl : traced) px_traced += tile_px(sharded ? ctx->tiles_host[sl] : sl);
+        ctx->stats_culled = (px_all - px_traced) * A.spp * nf;
+    }
+    A.trace_bpf = A.num_trace_tiles * A.spp;
+    A.num_batches = A.trace_bpf * nf;
+    auto magic = [](uint32_t d) { return d > 1u ? uint32_t(0x100000000ull / d) : 0xFFFFFFFFu; };      // d == 1: mulhi gives n - 1 (n > 0), corrected in the kernel
+    A.trace_bpf_magic = magic(A.trace_bpf ? A.trace_bpf : 1u); A.spp_magic = magic(A.spp); A.tiles_x_magic = magic(A.tiles_x);
+    if (A.num_batches == 0u) { A.trace_bpf = 1u; A.trace_bpf_magic = magic(1u); }      // every owned tile is culled (or there is none): nothing to trace, the resolve pass delivers the primed miss values
+    PlanInput in; std::memset(&in, 0, sizeof(in));
+    in.num_cus = uint32_t(ctx->num_cus > 0 ? ctx->num_cus : 256); in.frames = nf; in.tile_count = count; in.sharded = sharded; in.stats = stats;
+    in.traced_batches = A.num_batches; in.batch_size = ctx->batch_size;
+    if (count < 2u && nf == 1u && !stats) {       // a single whole frame: how many earlier launches are still in flight?
+        for (const auto& o : ctx->slots) if (o.side && o.used && hipEventQuery(o.done) == hipErrorNotReady) ++in.launches_in_flight;
+        (void)hipGetLastError();                  // hipErrorNotReady is an answer, not an error: do not leave it behind for the launch checks
+    }
+    const LaunchPlan P = plan_launch(ctx->tune, in);
+    if (P.error) return fail(ctx, PT_ERR_INVALID_ARG, P.error);
+    A.perm_rows = P.perm_rows; A.perm_rows_magic = magic(P.perm_rows); A.perm_cols = P.perm_cols; A.total_items = P.total_items;
+    A.chunk_items = P.chunk_items; A.xcd_span = P.xcd_span;
+    A.shade_threshold = P.shade_threshold; A.fill_threshold = P.fill_threshold; A.quad_live = P.quad_live; A.fork_shadow = P.fork_shadow;
+    A.rcp_short = (PtTune::pick(ctx->tune.bounded, 1u) != 0u && arith_is_bounded(ctx, ctx->pending_frames, nf)) ? 1u : 0u;      // knob BOUNDED = 0: always the general forms (tests)
+
+    // ---- prepare: frame slots (instrumented launches always use slot 0 and are not overlapped), traced-tile list ------------------------
+    ctx->num_slots = P.slots;
+    if (int rc = prepare_slots(ctx, P, A, nf, stats)) return rc;
+    PtContext::FrameSlot& sl = ctx->slots[stats ? 0 : (ctx->next_slot++ % uint32_t(P.slots))];
     A.prime = stats ? 1u : 0u;                   // instrumented launches start from a freshly primed prefix
     A.samples = sl.samples.ptr; A.queue = sl.queue.ptr; A.spill = sl.spill.ptr; A.raybuf = sl.rays.ptr;
     A.trace_slots = nullptr;
-    if (cull) {
-        // the list travels through a pinned staging buffer of the slot; it is rebuilt only when the rectangle (or the tile share) changes
-        const uint32_t key[8] = {rect.tx0, rect.ty0, rect.tx1, rect.ty1, A.width, A.height, ctx->pending_rank | (ctx->pending_count << 16), A.num_trace_tiles};
-        if (!sl.cull_valid || std::memcmp(key, sl.cull_key, sizeof key) != 0) {
-            if (!sl.trace_copied) PT_HIP(ctx, hipEventCreateWithFlags(&sl.trace_copied, hipEventDisableTiming));
-            else PT_HIP(ctx, hipEventSynchronize(sl.trace_copied));                   // the previous copy out of the staging buffer is done
-            if (sl.h_trace_cap < traced.size()) {
-                if (sl.h_trace) (void)hipHostFree(sl.h_trace);
-                sl.h_trace = nullptr; sl.h_trace_cap = 0;
-                PT_HIP(ctx, hipHostMalloc((void**)&sl.h_trace, std::max<size_t>(traced.size(), 1024) * sizeof(uint32_t), hipHostMallocDefault));
-                sl.h_trace_cap = std::max<size_t>(traced.size(), 1024);
-            }
-            PT_HIP(ctx, sl.trace_slots.ensure(std::max<size_t>(traced.size(), 1)));
-            if (!traced.empty()) std::memcpy(sl.h_trace, traced.data(), traced.size() * sizeof(uint32_t));
-            sl.cull_valid = false;
-        }
-    }
-    uint32_t stat_waves = 0;
+    const uint32_t cull_key[8] = {rect.tx0, rect.ty0, rect.tx1, rect.ty1, A.width, A.height, ctx->pending_rank | (ctx->pending_count << 16), A.num_trace_tiles};
+    if (cull) { if (int rc = stage_traced_tiles(ctx, sl, cull_key, traced)) return rc; }
     if (stats) {
-        stat_waves = grid_lanes / 64u;
+        const uint32_t stat_waves = P.grid * ptk::megakernel_block() / 64u;
         PT_HIP(ctx, ctx->d_wave_times.ensure(size_t(stat_waves) * ptk::kWaveTimeWords));
         A.wave_times = ctx->d_wave_times.ptr; ctx->wave_times_n = stat_waves;
     }
-    // Dependencies: scene uploads are host-synchronous, so the trace only has to wait for the resolve
-    // that last read this slot's sample buffer (NOT for the previous frame's resolve -- that is what
-    // lets consecutive frames overlap); the resolve on the main stream waits for the trace.
+
+    // ---- launch ---------------------------------------------------------------------------------------------------------------
+    // Dependencies: scene uploads are host-synchronous, so the trace only has to wait for the resolve that last read this slot's sample buffer (NOT
+    // for the previous frame's resolve -- that is what lets consecutive frames overlap); the resolve on the main stream waits for the trace.
     if (!ring) PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
     if (sl.used) PT_HIP(ctx, hipStreamWaitEvent(sl.side, sl.resolved, 0));
     if (cull) {
         if (!sl.cull_valid) {
             if (!traced.empty()) PT_HIP(ctx, hipMemcpyAsync(sl.trace_slots.ptr, sl.h_trace, traced.size() * sizeof(uint32_t), hipMemcpyHostToDevice, sl.side));
             PT_HIP(ctx, hipEventRecord(sl.trace_copied, sl.side));
-            const uint32_t key[8] = {rect.tx0, rect.ty0, rect.tx1, rect.ty1, A.width, A.height, ctx->pending_rank | (ctx->pending_count << 16), A.num_trace_tiles};
-            std::memcpy(sl.cull_key, key, sizeof key); sl.cull_valid = true; sl.num_trace_tiles = A.num_trace_tiles;
+            std::memcpy(sl.cull_key, cull_key, sizeof cull_key); sl.cull_valid = true; sl.num_trace_tiles = A.num_trace_tiles;
         }
         A.trace_slots = sl.trace_slots.ptr;
         A.trace_rect[0] = rect.tx0; A.trace_rect[1] = rect.tx1; A.trace_rect[2] = rect.ty0; A.trace_rect[3] = rect.ty1;
     }
     if (stats) {
-        // the counter blocks are zeroed on the stream the instrumented kernel runs on, behind everything that stream still has
-        // to wait for; the previous reader (pt_get_stats / pt_debug_*) copied them synchronously
+        // the counter blocks are zeroed on the stream the instrumented kernel runs on, behind everything that stream still has to wait for; the previous
+        // reader (pt_get_stats / pt_debug_*) copied them synchronously
         PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 24 * sizeof(unsigned long long), sl.side));
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(stat_waves) * ptk::kWaveTimeWords * 8u, sl.side));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(ctx->wave_times_n) * ptk::kWaveTimeWords * 8u, sl.side));
     }
     {   // per-frame parameters and targets into the slot's device arrays; a frame whose target a later frame of this launch
         // overwrites is marked (its result would not survive one-launch-per-frame rendering either)
@@ -498,7 +534,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         A.frames = sl.frame_params.ptr; A.outs = sl.frame_outs.ptr;
     }
     // timing ring: events tightly around the trace kernels on the stream they run on
-    PT_HIP(ctx, ptk::launch_trace(A, stats, grid, sl.side, ring ? e0 : nullptr, ring ? e1 : nullptr));
+    PT_HIP(ctx, ptk::launch_trace(A, stats, P.grid, sl.side, ring ? e0 : nullptr, ring ? e1 : nullptr));
     PT_HIP(ctx, hipEventRecord(sl.done, sl.side));
     PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.done, 0));
     PT_HIP(ctx, ptk::launch_resolve(A, ctx->stream));
@@ -1111,6 +1147,21 @@ int pt_debug_set_tune(PtContext* ctx, const char* name, uint32_t value) {
     uint32_t* knob = name ? ctx->tune.find(name) : nullptr;
     if (!knob) return fail(ctx, PT_ERR_INVALID_ARG, "pt_debug_set_tune: unknown knob");
     *knob = value;
+    return PT_OK;
+}
+
+/* diagnostics: the launch heuristics as a pure function (no GPU, no context: the measured defaults) -- what a launch of `frames` frames of a 1/tile_count
+ * share with `traced_batches` batches of 64 pixel-samples would be given */
+int pt_debug_launch_plan(uint32_t num_cus, uint32_t frames, uint32_t tile_count, uint32_t launches_in_flight, uint32_t traced_batches, uint32_t batch_size, uint32_t out[12]) {
+    if (!out || frames == 0u) return fail(nullptr, PT_ERR_INVALID_ARG, "pt_debug_launch_plan: bad arguments");
+    PlanInput in; std::memset(&in, 0, sizeof(in));
+    in.num_cus = num_cus; in.frames = frames; in.tile_count = tile_count ? tile_count : 1u; in.sharded = in.tile_count > 1u; in.stats = false;
+    in.launches_in_flight = launches_in_flight; in.traced_batches = traced_batches; in.batch_size = batch_size ? batch_size : 1u;
+    const LaunchPlan P = plan_launch(PtTune(), in);
+    if (P.error) return fail(nullptr, PT_ERR_INVALID_ARG, P.error);
+    const uint32_t v[12] = {P.grid, P.perm_rows, P.perm_cols, P.total_items, P.chunk_items, P.xcd_span, P.shade_threshold, P.fill_threshold, P.quad_live, P.fork_shadow,
+                            uint32_t(P.slots), uint32_t(P.setup_slots)};
+    std::memcpy(out, v, sizeof v);
     return PT_OK;
 }
 

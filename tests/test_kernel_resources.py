@@ -1,0 +1,91 @@
+"""What the compiler made of the megakernel, pinned (compile-only: hipcc cross-compiles gfx950 without a GPU).
+
+The kernel sits at exactly 80 vector registers -- six wavefronts per SIMD -- with no scratch memory, and its register allocation is fragile
+(tools/isa_stats.sh): an innocent edit of the launch loop can cost a spill or a wavefront of occupancy without failing any parity test.
+The second test guards the tree against the one inline-asm pattern that hung a GPU in round 4: a memory LOAD written as an asm statement without an
+output operand -- the compiler then considers the destination register free while the load is still in flight (tools/README.md)."""
+import glob
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "raytracer-public_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+
+
+@pytest.mark.skipif(HIPCC is None, reason="hipcc is missing")
+def test_megakernel_registers_scratch_and_occupancy_are_pinned():
+    out = subprocess.run(["make", "-s", "-C", CSRC, "resource-usage"], capture_output=True, text=True, timeout=600)
+    text = out.stdout + out.stderr
+    blocks = re.split(r"remark: Function Name: ", text)
+    seen = {}
+    for b in blocks[1:]:
+        name = b.split()[0]
+        m = re.match(r"_ZN3ptk18trace_paths_kernelILb([01])ELb([01])E", name)
+        if not m:
+            continue
+        f = {k: int(v) for k, v in re.findall(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", b)}
+        seen[(int(m.group(1)), int(m.group(2)))] = f
+    assert set(seen) == {(0, 0), (0, 1), (1, 0), (1, 1)}, sorted(seen)            # <STATS, BOUNDED>: all four variants are compiled
+    for bounded in (0, 1):                                                        # the production variants (no counters)
+        f = seen[(0, bounded)]
+        assert f["VGPRs"] <= 80, f
+        assert f["ScratchSize [bytes/lane]"] == 0, f
+        assert f["VGPRs Spill"] == 0, f
+        assert f["Occupancy [waves/SIMD]"] >= 6, f
+        assert f["SGPRs Spill"] <= 24, f                                           # 15-19 today, all of them in the cold paths (deep-stack spill area, launch prologue)
+        assert f["LDS Size [bytes/block]"] <= 160 * 1024 // 24, f                  # six single-wave workgroups per SIMD fit the CU's LDS
+
+
+LOADS = re.compile(r"\b(ds_read\w*|ds_load\w*|global_load\w*|buffer_load\w*|flat_load\w*|scratch_load\w*|s_load\w*|s_buffer_load\w*|global_atomic\w*|ds_\w*_rtn\w*)\b")
+
+
+def _asm_statements(src):
+    """(line, string part, [operand sections]) of every asm statement: text up to the matching parenthesis, split at top-level colons outside strings."""
+    for m in re.finditer(r"\basm\s*(volatile)?\s*\(", src):
+        i, depth, in_str, sections, cur = m.end(), 1, False, [], []
+        while i < len(src) and depth:
+            ch = src[i]
+            if in_str:
+                cur.append(ch)
+                if ch == "\\":
+                    cur.append(src[i + 1]); i += 1
+                elif ch == '"':
+                    in_str = False
+            elif ch == '"':
+                in_str = True; cur.append(ch)
+            elif ch == "(":
+                depth += 1; cur.append(ch)
+            elif ch == ")":
+                depth -= 1
+                if depth:
+                    cur.append(ch)
+            elif ch == ":" and depth == 1 and src[i + 1] != ":" and src[i - 1] != ":":
+                sections.append("".join(cur)); cur = []
+            else:
+                cur.append(ch)
+            i += 1
+        sections.append("".join(cur))
+        yield src.count("\n", 0, m.start()) + 1, sections[0], sections[1:]
+
+
+def test_no_asm_memory_load_without_an_output_operand():
+    checked = 0
+    for path in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(CSRC, "*.cpp"))):
+        src = open(path, encoding="utf-8", errors="replace").read()
+        for line, text, ops in _asm_statements(src):
+            if not LOADS.search(text):
+                continue
+            checked += 1
+            outputs = ops[0].strip() if ops else ""
+            assert outputs, "%s:%d: an asm statement loads from memory but declares no output operand: the destination register is dead to the compiler while the load is in flight" % (os.path.basename(path), line)
+            # the loaded registers must not be handed out to the inputs either (early clobber), and the data must have arrived when the statement ends
+            for dst in re.findall(r'"(=[^"]*)"', outputs):
+                if "v" in dst:
+                    assert "&" in dst, "%s:%d: a loaded vector register is not an early-clobber output (\"=&v\")" % (os.path.basename(path), line)
+            assert re.search(r"s_waitcnt\s+(lgkmcnt|vmcnt)\(0\)", text), "%s:%d: the asm statement does not wait for its own load" % (os.path.basename(path), line)
+    assert checked >= 1          # the hand-written pop loop (pt_megakernel_loop.inc) is such a statement

@@ -1,0 +1,83 @@
+"""The megakernel's launch heuristics (pt_api.cpp::plan_launch) as a pure function, pinned for the launch shapes bench.py uses: a lone whole frame,
+the driver's 20-frame launch, the sustained leg's 32-frame launches, the N = 8 run's launches of five 1/8 shares and the N = 2 run's of 64 halves.
+No GPU: pt_debug_launch_plan needs no context.  (What the numbers were measured with: DESIGN.md section 5, tools/sweep.sh, tools/pipe_sweep.sh.)"""
+import ctypes as C
+import importlib
+
+import pytest
+
+rt = importlib.import_module("raytracer-public_amd")
+
+CUS = 256
+FULL_GRID = CUS * 6 * 4            # six single-wavefront workgroups per SIMD
+C2_TILES, C2_TRACED, SPP = 240 * 135, 97 * 92, 4      # 1920 x 1080 in 8 x 8 tiles; a dragon-class rectangle of traced tiles (its size does not enter the heuristics)
+NAMES = ("grid", "perm_rows", "perm_cols", "total_items", "chunk_items", "xcd_span", "shade_threshold", "fill_threshold", "quad_live", "fork_shadow", "slots", "setup_slots")
+
+
+def plan(frames, tile_count=1, in_flight=0, traced_tiles=C2_TRACED, batch_size=None):
+    out = (C.c_uint32 * 12)()
+    batches = frames * (traced_tiles // tile_count) * SPP
+    rc = rt.lib.pt_debug_launch_plan(C.c_uint32(CUS), C.c_uint32(frames), C.c_uint32(tile_count), C.c_uint32(in_flight), C.c_uint32(batches), C.c_uint32(batch_size or frames), out)
+    assert rc == 0, rt.lib.pt_last_error(None)
+    d = dict(zip(NAMES, out))
+    d["batches"] = batches
+    return d
+
+
+def check_common(p):
+    assert p["chunk_items"] == 128                                   # two batches of 64 per claim
+    assert (p["shade_threshold"], p["fill_threshold"], p["quad_live"], p["fork_shadow"]) == (16, 4, 16, 2)
+    assert p["total_items"] == p["perm_rows"] * p["perm_cols"] * 64
+    assert p["batches"] <= p["perm_rows"] * p["perm_cols"] < p["batches"] + p["perm_rows"]      # the transposition covers every batch, with less than one row of padding
+    assert p["setup_slots"] >= p["slots"] >= 1
+    if p["xcd_span"]:
+        assert p["xcd_span"] % p["chunk_items"] == 0 and 8 * p["xcd_span"] >= p["total_items"]
+
+
+def test_lone_whole_frame_and_one_render_per_frame():
+    p = plan(1)
+    check_common(p)
+    assert p["grid"] == FULL_GRID                                    # a lone frame keeps the whole grid ...
+    assert p["perm_rows"] == 128 and p["xcd_span"] == 0              # ... cuts the frame into 128 segments (balance), one queue
+    assert p["slots"] == 6
+    for in_flight, div in ((1, 2), (2, 3), (3, 4), (5, 4)):          # ... and shrinks with the launches already in flight (the reference's call shape without waits)
+        assert plan(1, in_flight=in_flight)["grid"] == -(-FULL_GRID // div)
+
+
+def test_the_drivers_twenty_frame_launch():
+    p = plan(20)
+    check_common(p)
+    assert p["grid"] == FULL_GRID
+    assert p["perm_rows"] == 20                                      # one row per frame: all frames walk the image in step
+    assert p["xcd_span"] != 0                                        # XCD-aware queue from 8 frames of work on
+    assert p["slots"] == 4
+
+
+def test_sustained_thirty_two_frame_launches():
+    p = plan(32)
+    check_common(p)
+    assert p["grid"] == FULL_GRID and p["perm_rows"] == 32 and p["xcd_span"] != 0
+    assert p["slots"] == 3                                           # a long launch only needs its tail covered by the next one
+
+
+def test_five_eighth_shares_per_launch():
+    p = plan(5, tile_count=8)
+    check_common(p)
+    assert p["grid"] == FULL_GRID                                    # grid / 4 for ONE 1/8 share, times five shares: the whole grid again
+    assert plan(1, tile_count=8)["grid"] == FULL_GRID // 4
+    assert p["perm_rows"] == 64 * 5 and p["xcd_span"] == 0           # 5/8 of a frame of work: a short launch
+    assert p["slots"] == 8                                           # small sharded launches need several in flight to fill the chip
+    assert plan(5, tile_count=8, batch_size=20)["setup_slots"] == 8  # the slots are set up for a full batch of the current setting as well
+
+
+def test_sixty_four_halves_per_launch():
+    p = plan(64, tile_count=2)
+    check_common(p)
+    assert p["grid"] == FULL_GRID and p["perm_rows"] == 64 and p["xcd_span"] != 0
+    assert p["slots"] == 3
+
+
+def test_a_launch_too_large_for_the_queue_cursor_is_refused():
+    out = (C.c_uint32 * 12)()
+    rc = rt.lib.pt_debug_launch_plan(C.c_uint32(CUS), C.c_uint32(256), C.c_uint32(1), C.c_uint32(0), C.c_uint32(0x03FFFFF0), C.c_uint32(256), out)
+    assert rc != 0
