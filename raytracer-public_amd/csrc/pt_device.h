@@ -58,10 +58,6 @@ __device__ __forceinline__ float half_hi(uint32_t w) { return (float)__builtin_b
 __device__ __forceinline__ float half_lo_minus(uint32_t w, float o) { float r; asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(o)); return r; }
 __device__ __forceinline__ float half_hi_minus(uint32_t w, float o) { float r; asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(o)); return r; }
 
-// float(low / high half of w) * a - c in one instruction (the FAST variant's slab test)
-__device__ __forceinline__ float half_lo_fms(uint32_t w, float a, float c) { float r; asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(a), "v"(c)); return r; }
-__device__ __forceinline__ float half_hi_fms(uint32_t w, float a, float c) { float r; asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(a), "v"(c)); return r; }
-
 constexpr float kInfT = 1e30f;          // renderer.wgsl:64
 constexpr float kTriEps = 1e-7f;        // renderer.wgsl:178
 constexpr uint32_t kLeaf = 0x80000000u;
@@ -143,17 +139,6 @@ __device__ __forceinline__ unsigned long long slab_sel(const F3& o, const F3& in
     const uint32_t bx = __builtin_amdgcn_perm(w1, w0, sel.x), by = __builtin_amdgcn_perm(w2, w0, sel.y), bz = __builtin_amdgcn_perm(w2, w1, sel.z);
     const float nx = half_lo_minus(bx, o.x) * inv.x, ny = half_lo_minus(by, o.y) * inv.y, nz = half_lo_minus(bz, o.z) * inv.z;
     const float fx = half_hi_minus(bx, o.x) * inv.x, fy = half_hi_minus(by, o.y) * inv.y, fz = half_hi_minus(bz, o.z) * inv.z;
-    const float tmin = wmax(wmax(nx, ny), nz);
-    const float tmax = wmin(wmin(fx, fy), fz);
-    tmin_out = tmin;
-    return __builtin_amdgcn_ballot_w64(tmax >= wmax(tmin, 0.0f)) & __builtin_amdgcn_ballot_w64(tmin < best);
-}
-// FAST variant (PT_FLAG_FAST: spends BASELINE's 1e-4 tolerance instead of bit-exactness): every bound as ONE fused operation, fma(bound, inv, -(o * inv)) with
-// o * inv kept per ray -- 14 instructions per box instead of 20, one rounding instead of two per bound
-__device__ __forceinline__ unsigned long long slab_sel_fast(const F3& oi, const F3& inv, const RaySel& sel, uint32_t w0, uint32_t w1, uint32_t w2, float best, float& tmin_out) {
-    const uint32_t bx = __builtin_amdgcn_perm(w1, w0, sel.x), by = __builtin_amdgcn_perm(w2, w0, sel.y), bz = __builtin_amdgcn_perm(w2, w1, sel.z);
-    const float nx = half_lo_fms(bx, inv.x, oi.x), ny = half_lo_fms(by, inv.y, oi.y), nz = half_lo_fms(bz, inv.z, oi.z);
-    const float fx = half_hi_fms(bx, inv.x, oi.x), fy = half_hi_fms(by, inv.y, oi.y), fz = half_hi_fms(bz, inv.z, oi.z);
     const float tmin = wmax(wmax(nx, ny), nz);
     const float tmax = wmin(wmin(fx, fy), fz);
     tmin_out = tmin;
