@@ -307,7 +307,7 @@ struct PlanInput {
     uint32_t traced_batches;     // (frame, traced tile, sample) batches of 64 pixel-samples in the launch
     uint32_t batch_size;         // pt_set_batch of the context: what a FULL launch of the current setting carries
 };
-// ... and what they decide (measured defaults, each overridable through PtTune; sources: DESIGN.md section 5, tools/sweep.sh)
+// ... and what they decide (measured defaults, each overridable through PtTune; sources: DESIGN.md section 6.1, profiles/HISTORY.md, tools/sweep.sh)
 struct LaunchPlan {
     uint32_t grid;               // workgroups of the persistent kernel
     uint32_t perm_rows, perm_cols, total_items, chunk_items, xcd_span;       // the queue's walk through the batches
