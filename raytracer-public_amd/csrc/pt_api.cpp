@@ -41,16 +41,16 @@ struct DevBuf {
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto,
-             slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto, fork = kAuto, bounded = kAuto, merge = kAuto;
+             slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto, fork = kAuto, bounded = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}, {"FORK", &PtTune::fork}, {"BOUNDED", &PtTune::bounded}, {"MERGE", &PtTune::merge}};
+            {"FILL", &PtTune::fill}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}, {"FORK", &PtTune::fork}, {"BOUNDED", &PtTune::bounded}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL", "STATSBATCH", "QUAD", "FORK", "BOUNDED", "MERGE"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL", "STATSBATCH", "QUAD", "FORK", "BOUNDED"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -484,7 +484,6 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     A.perm_rows = P.perm_rows; A.perm_rows_magic = magic(P.perm_rows); A.perm_cols = P.perm_cols; A.total_items = P.total_items;
     A.chunk_items = P.chunk_items; A.xcd_span = P.xcd_span;
     A.shade_threshold = P.shade_threshold; A.fill_threshold = P.fill_threshold; A.quad_live = P.quad_live; A.fork_shadow = P.fork_shadow;
-    A.merge = (A.ref_mode || A.quad_live == 0u) ? 0u : PtTune::pick(ctx->tune.merge, PT_MERGE);          // drain merge between the wavefronts of a workgroup (needs PT_MEGA_BLOCK > 64)
     A.rcp_short = (PtTune::pick(ctx->tune.bounded, 1u) != 0u && arith_is_bounded(ctx, ctx->pending_frames, nf)) ? 1u : 0u;      // knob BOUNDED = 0: always the general forms (tests)
 
     // ---- prepare: frame slots (instrumented launches always use slot 0 and are not overlapped), traced-tile list ------------------------

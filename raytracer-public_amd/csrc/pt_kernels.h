@@ -35,17 +35,12 @@
 #ifndef PT_QUAD_LIVE
 #define PT_QUAD_LIVE 16            // paths a wavefront may hold when it re-seats them (16 quads per wavefront)
 #endif
-#ifndef PT_MERGE
-#define PT_MERGE 1                 // drain merge (pt_megakernel.hip; needs PT_MEGA_BLOCK > 64): a wavefront about to re-seat <= 16 paths gives them to a sibling that still runs one ray per lane
-#endif
 #ifndef PT_FILL_THRESHOLD
 #define PT_FILL_THRESHOLD 4        // hand out ready camera rays when this many lanes of a wavefront are without a path (a fetch from the ray buffer is cheap: 4 beats 8 by 2 %)
 #endif
 
 namespace ptk {
 
-constexpr uint32_t kMergeRecWords = 28;  // a path handed to a sibling wavefront: o, d, best_t, best_tri, cur, sp, T, rad, d_next, contrib, key, item, bounce word, phase, stack column (27 words used)
-constexpr uint32_t kMergeMaxPaths = 16;  // = the most paths a wavefront re-seats (16 quads)
 constexpr uint32_t kWaveTimeWords = 24;  // STATS diagnostics: 64-bit words per wavefront in RenderArgs::wave_times
 #define PT_MAX_BATCH 256    // frames per persistent launch (their per-frame parameters live in a small device array)
 // Per-frame part of the UBO for a batched launch (several consecutive frames traced by one persistent launch).
@@ -112,7 +107,6 @@ struct RenderArgs {
     uint32_t  shade_threshold, fill_threshold;
     uint32_t  fork_shadow;      // quad mode: shadow rays of paths that go on are traced by idle quads, next to the path's next ray (0: by the path itself, in turn)
     uint32_t  quad_live;        // re-seat the paths one per quad once the wavefront has nothing left to start and holds at most this many (0: never)
-    uint32_t  merge;            // drain merge between the wavefronts of a workgroup (pt_megakernel.hip): 0 off
     // batched launch: frames[i] / outs[i] for i < num_frames; items of frame i are batches [i*batches_per_frame, ...)
     const FrameParams* frames; float4* const* outs;     // device arrays of the frame slot, filled by launch_frame_params
     uint32_t  num_frames, batches_per_frame;

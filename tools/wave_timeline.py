@@ -60,6 +60,5 @@ print('wavefronts that re-seated their paths (one ray per quad of lanes): %d' % 
 print('wavefronts still running at us after the first began: ' + ', '.join('%d: %d' % (t, int((end > t).sum())) for t in np.percentile(end, [10, 30, 50, 70, 90, 97]).astype(int)))
 print('longest path %d traversal steps, longest ray %d; paths >= 512 steps: %d, >= 1024: %d' % (dbg[12], dbg[13], dbg[14], dbg[15]))
 print('paths >= 512 steps: %.1f %% of their traversal steps belong to shadow rays (%d of %d)' % (100.0 * dbg[17] / max(int(dbg[18]), 1), dbg[17], dbg[18]))
-print('quad mode: shadow rays handed to an idle quad %d, no idle quad %d, paths that waited for their shadow ray %d; shadow rays in all %d' % (dbg[19], int(dbg[20]) & 0xffffffff, dbg[21], st['rays_shadow']))
+print('quad mode: shadow rays handed to an idle quad %d, no idle quad %d, paths that waited for their shadow ray %d; shadow rays in all %d' % (dbg[19], dbg[20], dbg[21], st['rays_shadow']))
 print('after a wavefront had nothing left to start: %.1f %% of its (path x iteration) slots were paths waiting for their forked shadow ray (%d of %d)' % (100.0 * dbg[22] / max(int(dbg[23]), 1), dbg[22], dbg[23]))
-print('drain merge: %d paths given to a sibling wavefront that still stepped one ray per lane' % (int(dbg[20]) >> 32))
