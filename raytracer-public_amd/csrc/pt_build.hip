@@ -110,16 +110,17 @@ __global__ __launch_bounds__(256) void morton_kernel(const float* __restrict__ t
 // above those of infinity, so "small enough" is one unsigned compare on the host (what the traversal's short reciprocal may assume, pt_api.cpp)
 __global__ __launch_bounds__(256) void tri_records_kernel(const float* __restrict__ tris, uint32_t n, float4* __restrict__ rec, uint32_t* __restrict__ edge_max) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const float* p = tris + (size_t)t * 9;
+    const bool live = t < n;                       // (no early return: the lanes past n of the last wavefront take part in the reduction below, with 0)
+    const float* p = tris + (size_t)(live ? t : 0u) * 9;
     const F3 v0 = f3(p[0], p[1], p[2]);
     const F3 e1 = f3(p[3] - p[0], p[4] - p[1], p[5] - p[2]), e2 = f3(p[6] - p[0], p[7] - p[1], p[8] - p[2]);
     if (edge_max) {
         auto bits = [](float v) { return __float_as_uint(v) & 0x7fffffffu; };
-        uint32_t m = max(max(max(bits(e1.x), bits(e1.y)), max(bits(e1.z), bits(e2.x))), max(bits(e2.y), bits(e2.z)));
-        for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));      // (lanes past n have left: a partial last wavefront reads its own value back)
+        uint32_t m = live ? max(max(max(bits(e1.x), bits(e1.y)), max(bits(e1.z), bits(e2.x))), max(bits(e2.y), bits(e2.z))) : 0u;
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
         if ((threadIdx.x & 63u) == 0u) atomicMax(edge_max, m);
     }
+    if (!live) return;
     const F3 c = cross3(e1, e2);
     const float inv = 1.0f / sqrtf((c.x * c.x + c.y * c.y) + c.z * c.z);
     float4* r = rec + (size_t)t * 4;
