@@ -602,4 +602,23 @@ def test_error_paths(rt, gpu_ctx):
     with pytest.raises(rt.PtError) as e2:
         fresh.set_bvh4(bad)
     assert e2.value.code == 5
+    # a tile share count beyond what a running accumulation can remember (12 + 12 bits, as pt_set_accum) is refused by pt_render too
+    with pytest.raises(rt.PtError) as e3:
+        fresh.render(fresh.make_params(64, 64, mode=rt.PT_MODE_PATH, tile_rank=0, tile_count=4096))
+    assert e3.value.code == 1 and "4095" in str(e3.value)                 # PT_ERR_INVALID_ARG
+    fresh.render(fresh.make_params(64, 64, mode=rt.PT_MODE_PATH, tile_rank=3, tile_count=4095))       # the largest count is fine
+    # a checkpoint whose `samples` disagrees with the sample count stored in its own data is refused (first / last pixel's w)
+    for f in range(3):
+        fresh.render(fresh.make_params(40, 24, mode=rt.PT_MODE_PATH, spp=2, max_bounces=2, frame=f, accumulate=True))
+    info, dump = fresh.read_accum()
+    assert info.samples == 6 and dump[3] == np.float32(6) and dump[-1] == np.float32(6)
+    info.samples = 4
+    with pytest.raises(rt.PtError) as e4:
+        fresh.set_accum(info, dump)
+    assert e4.value.code == 1 and "samples" in str(e4.value)
+    info.samples = 6
+    tampered = dump.copy(); tampered[-1] = np.float32(5)
+    with pytest.raises(rt.PtError):
+        fresh.set_accum(info, tampered)
+    fresh.set_accum(info, dump)                                           # the untouched dump is accepted
     fresh.close()
