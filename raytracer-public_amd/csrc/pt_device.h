@@ -21,19 +21,19 @@ __device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y 
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ F3 cross3(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 // ---- short forms of the correctly rounded reciprocal and square root --------------------------------------------------------
-// 1.0f / d for 2^-64 <= |d| < 2^64, bit-identical to the compiler's IEEE division in 7 instructions instead of 11: for such a denominator (and the
-// numerator 1.0) the two v_div_scale of the compiler's sequence return their inputs unscaled, its v_div_fmas is a plain fma and v_div_fixup returns
-// the quotient -- what remains is v_rcp + 6 fma, written out here (the multiplication by the numerator is exact and dropped).
+// 1.0f / d for 2^-64 <= |d| < 2^64 in THREE instructions instead of the compiler's eleven: v_rcp_f32 and ONE Newton step with the exact residual,
+// r + r * fma(-d, r, 1).  The compiler's IEEE sequence (v_div_scale x2, v_rcp, four fma, v_mul, v_div_fmas, v_div_fixup) scales operands near the ends of
+// the exponent range and patches zero / infinity / NaN -- nothing an operand of ordinary size needs -- and then refines twice more than gfx950's v_rcp_f32
+// (1 ulp) requires: the residual of a reciprocal cannot come closer to a rounding boundary than one step resolves.  That is not taken on trust:
+// tools/probes/rcp_exact.hip compares this form with `1.0f / x` over EVERY f32 bit pattern of the range on the GPU (2,164,260,864 patterns, 0 differences,
+// profiles/r05_d3_rcp3_exact.txt) -- so it IS the IEEE quotient there, bit for bit, on this hardware (the library is built for gfx950 only).
 // sqrtf(x) for x == 0 or 2^-64 <= x < 2^64 in 9 instructions instead of 16: the compiler's sequence without its scaling of small operands and its
-// zero / infinity fix-up -- v_sqrt, then the neighbours one ulp down and up are tried against the exact residuals.
-// Both are correctly rounded, so they equal the oracle's IEEE operations bit for bit; tools/probes/rcp_exact.hip compares them with `1.0f / x` and
-// `sqrtf(x)` over EVERY f32 bit pattern of those ranges.  Outside them the general forms are used: the megakernel is compiled in two variants
-// (BOUNDED), and the host picks the short one only where it can bound every operand (pt_api.cpp::arith_is_bounded).
+// zero / infinity fix-up -- v_sqrt, then the neighbours one ulp down and up are tried against the exact residuals (same probe, 0 differences).
+// Outside those ranges the general forms are used: the megakernel is compiled in two variants (BOUNDED), and the host picks the short one only where it
+// can bound every operand (pt_api.cpp::arith_is_bounded).
 __device__ __forceinline__ float rcp_normal(float d) {
-    float r = __builtin_amdgcn_rcpf(d);
-    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-    const float q = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-    return __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), r, q);
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
 }
 __device__ __forceinline__ float sqrt_normal(float x) {
     float s = __builtin_amdgcn_sqrtf(x);
