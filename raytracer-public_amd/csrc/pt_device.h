@@ -177,17 +177,22 @@ __device__ __forceinline__ void sincos_2pi(float u, float& c, float& s) {
     c = (k == 0) ? cy : (k == 1) ? -sy : (k == 2) ? -cy : sy;
     s = (k == 0) ? sy : (k == 1) ? cy : (k == 2) ? -sy : -cy;
 }
-template <bool B = false> __device__ __forceinline__ F3 cosine_dir(F3 n, float u1, float u2) {
+// cosine-weighted direction around n in two halves: the sample in the local frame (independent of n: the megakernel's shade pass computes it while the hit
+// triangle's normal is still on its way from memory) and its transfer into the branch-free orthonormal basis of n (Duff et al.)
+template <bool B = false> __device__ __forceinline__ F3 cosine_local(float u1, float u2) {
     float c, s; sincos_2pi(u2, c, s);
     const float r = sqrt_f<B>(u1);
-    const float lx = r * c, ly = r * s, lz = sqrt_f<B>(1.0f - u1);
+    return f3(r * c, r * s, sqrt_f<B>(1.0f - u1));
+}
+template <bool B = false> __device__ __forceinline__ F3 cosine_world(F3 n, F3 l) {
     const float sign = copysignf(1.0f, n.z);
     const float a = B ? -rcp_normal(sign + n.z) : -1.0f / (sign + n.z);        // (the quotient's sign is exact: -(1 / x) and (-1) / x are the same bits)
     const float b = n.x * n.y * a;
     const F3 t = f3(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
     const F3 bt = f3(b, sign + n.y * n.y * a, -n.y);
-    return (t * lx + bt * ly) + n * lz;
+    return (t * l.x + bt * l.y) + n * l.z;
 }
+template <bool B = false> __device__ __forceinline__ F3 cosine_dir(F3 n, float u1, float u2) { return cosine_world<B>(n, cosine_local<B>(u1, u2)); }
 
 // n / d and n % d for a divisor whose magic = floor(2^32 / d) comes from the host: estimate by multiply-high (never too large, at
 // most one too small), one correction
