@@ -2,6 +2,9 @@
 # The end-of-round records of one session (GPU box): the driver's command, the default run, every BASELINE configuration, wave timelines, the reference's own workload,
 # the launch stress, scene build times -> gpurun_out/r05_*; the caller copies what it keeps into profiles/.
 cd $GRAFT_REPO_ROOT
+# the counter passes FIRST: bench.py prints roofline fractions only from a counter file whose tag matches the kernel sources it runs
+tools/pmc_bench.sh r05_pmc > gpurun_out/r05_pmc.log 2>&1; cp gpurun_out/r05_pmc/pmc_bench.json profiles/r05_pmc_bench.json && echo "pmc ok"
+cd $GRAFT_REPO_ROOT
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_n1_steps20.json 2> gpurun_out/r05_bench_n1_steps20.err; echo "bench20 rc=$?"
 timeout -k 10 300 python bench.py > gpurun_out/r05_bench_n1_default.json 2> gpurun_out/r05_bench_n1_default.err; echo "bench256 rc=$?"
 timeout -k 10 200 python3 tools/config_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_configs.txt; cat gpurun_out/r05_configs.txt
