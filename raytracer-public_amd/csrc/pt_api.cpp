@@ -959,7 +959,7 @@ int pt_render(PtContext* ctx, const PtRenderParams* p) {
     A.width = p->width; A.height = p->height; A.focal = p->focal; A.aspect = p->aspect;
     std::memcpy(A.cam, p->cam_pos, 12); std::memcpy(A.quat, p->cam_quat, 16);
     A.num_tris = p->num_tris; A.frame = p->frame;
-    A.tri_gate = p->num_tris < ctx->num_tris ? 4u * p->num_tris : 0xFFFFFFFFu;
+    A.tri_gate = p->num_tris < ctx->num_tris ? (0x80000000u | (4u * p->num_tris)) : 0xFFFFFFFFu;
     A.root_ref = ctx->wide_meta.root_ref; std::memcpy(A.root_box, ctx->wide_meta.root_box, 12);
     A.root_degenerate = ctx->wide_meta.root_degenerate ? 1u : 0u;
     A.spheres = ctx->d_spheres.ptr; A.num_spheres = brute ? ctx->num_spheres : 0u; A.brute = brute ? 1u : 0u;

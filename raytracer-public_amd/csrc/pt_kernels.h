@@ -63,7 +63,7 @@ struct RenderArgs {
                                 // child references are positions in it in 16-byte units (packed references, pt_host.h)
     uint32_t      node_off;
     uint32_t      rcp_short;    // 1: the operands of every reciprocal and square root of this launch are bounded (pt_api.cpp::arith_is_bounded): launch_trace picks the BOUNDED kernel variant (short forms, pt_device.h)
-    uint32_t      tri_gate;     // 4 * numTris (16-byte units) when the UBO's numTris is smaller than the uploaded triangle count (leaves past it are entered, not tested), else 0xFFFFFFFF
+    uint32_t      tri_gate;     // the leaf reference of triangle numTris (0x80000000 | 4 * numTris) when the UBO's numTris is smaller than the uploaded triangle count (leaves from it on are entered, not tested), else 0xFFFFFFFF
     // device scene, reference layouts (literal packet kernel, LBVH build, readback)
     const uint32_t* bvh4_ref;   // u32[1 + 8*M]   renderer.wgsl:91-111
     const float*    tris9;      // f32[9*N]       renderer.wgsl:82-89

@@ -37,7 +37,7 @@ def test_megakernel_registers_scratch_and_occupancy_are_pinned():
         assert f["ScratchSize [bytes/lane]"] == 0, f
         assert f["VGPRs Spill"] == 0, f
         assert f["Occupancy [waves/SIMD]"] >= 6, f
-        assert f["SGPRs Spill"] <= 24, f                                           # 15-21 today, all of them in the cold paths (deep-stack spill area, launch prologue)
+        assert f["SGPRs Spill"] <= 24, f                                           # 15-21 over round 5, all of them in the cold paths (deep-stack spill area, launch prologue)
         assert f["LDS Size [bytes/block]"] <= 160 * 1024 // 24, f                  # six single-wave workgroups per SIMD fit the CU's LDS
 
 
