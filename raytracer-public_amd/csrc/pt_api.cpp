@@ -344,7 +344,8 @@ LaunchPlan plan_launch(const PtTune& tune, const PlanInput& in) {
     // nodes they pull through L2.  Long launches take one row per frame (few places in flight = locality); short launches cut every frame into 128
     // segments (fine interleave of object and background tiles = balance when each wavefront only sees a few chunks).  tools/sweep.sh ROWS
     const uint32_t work8 = nf * 8u / count;
-    P.perm_rows = PtTune::pick(tune.rows, work8 >= 64u ? nf : (work8 >= 8u ? 128u * nf : 64u * nf));
+    // (one row per frame from 3 frames of work on: launches of 3 .. 7 frames of work 1 .. 7 % faster than with 128 segments per frame, profiles/r05_m2_midsize_rows.txt)
+    P.perm_rows = PtTune::pick(tune.rows, work8 >= 24u ? nf : (work8 >= 8u ? 128u * nf : 64u * nf));
     if (P.perm_rows < 1u) P.perm_rows = 1u;
     if (P.perm_rows > 4096u) P.perm_rows = 4096u;
     P.perm_cols = (in.traced_batches + P.perm_rows - 1u) / P.perm_rows;
