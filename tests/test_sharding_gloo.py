@@ -149,9 +149,9 @@ def test_bench_schedule_for_the_drivers_own_sharded_command():
     """`--gpus 8 --steps 20 --warmup 5`: four launches of five share-frames (was 10 / 8 / 2), the warm-up 2 / 1 / 1 / 1."""
     bench = _bench_module()
     cap = min(32 * 8, 256, 20)
-    assert [nf for _, nf in bench.schedule(20, cap, 8, False)] == [5, 5, 5, 5]
-    assert [nf for _, nf in bench.schedule(5, cap, 8, False)] == [2, 1, 1, 1]
-    assert [nf for _, nf in bench.schedule(256, 256, 8, False)] == [64, 64, 64, 64]
+    assert [nf for _, nf in bench.schedule(20, cap, 8, False)] == [7, 7, 6]
+    assert [nf for _, nf in bench.schedule(5, cap, 8, False)] == [2, 2, 1]
+    assert [nf for _, nf in bench.schedule(256, 256, 8, False)] == [86, 85, 85]
 
 
 def test_bench_submit_launches_is_the_sequence_both_callers_replay():
