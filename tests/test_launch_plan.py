@@ -86,6 +86,24 @@ def test_mid_size_launches_take_one_row_per_frame_from_three_frames_of_work():
         assert (p["xcd_span"] != 0) == (frames * 8 // tile_count >= 64)
 
 
+def test_plan_invariants_over_random_launch_shapes():
+    # whatever the shape, the plan covers every batch exactly once (plus less than a row of padding), keeps chunks whole batches, never leaves the grid empty and
+    # never lets the 32-bit queue cursor wrap
+    import random
+    rnd = random.Random(5)
+    for _ in range(400):
+        tile_count = rnd.choice((1, 1, 1, 2, 3, 4, 8, 16))
+        frames = rnd.choice((1, 2, 3, 5, 8, 13, 20, 32, 64, 100, 256))
+        traced = rnd.randint(1, C2_TILES)
+        p = plan(frames, tile_count=tile_count, in_flight=rnd.randint(0, 6), traced_tiles=max(traced, tile_count), batch_size=rnd.choice((None, 256)))
+        check_common(p)
+        assert 1 <= p["grid"] <= FULL_GRID
+        assert p["chunk_items"] % 64 == 0 and p["total_items"] % 64 == 0
+        assert 1 <= p["perm_rows"] <= 4096
+        assert p["total_items"] + (p["grid"] + 1) * p["chunk_items"] <= 0xFFFFFFFF
+        assert 1 <= p["slots"] <= 8
+
+
 def test_a_launch_too_large_for_the_queue_cursor_is_refused():
     out = (C.c_uint32 * 12)()
     rc = rt.lib.pt_debug_launch_plan(C.c_uint32(CUS), C.c_uint32(256), C.c_uint32(1), C.c_uint32(0), C.c_uint32(0x03FFFFF0), C.c_uint32(256), out)
