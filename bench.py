@@ -19,8 +19,10 @@ overlaps the trace of launch b+1.  Total work per step is fixed -> "scaling": "s
 Every run checks one TIMED frame against the CPU oracle on a fixed pixel grid (every 4th pixel in x and y, all samples,
 bit for bit) and prints "verified": true; a mismatch ends the run with a non-zero status and no result line.
 
-The timed region (exactly K steps between barriers + synchronisations, max over ranks) is repeated --reps times (default 5;
-SURVEY 8d asks for at least 3) after the warm-up; `value` / `ms_per_step` are the MEDIAN repetition, `ms_per_step_min_max` the spread.
+The timed region (exactly K steps between barriers + synchronisations, max over ranks) is repeated --reps times (default 9;
+SURVEY 8d asks for at least 3) after the warm-up; `value` / `ms_per_step` are the MEDIAN repetition, `ms_per_step_min_max` the spread, `ms_per_step_all`
+every repetition in order.  (Nine since round 5: behind a 5-step warm-up the chip is still ramping -- twelve repetitions of the driver's command read 0.777, 0.727, 0.721,
+0.708, 0.717, 0.714, 0.705, 0.707, 0.705, 0.711, 0.703, 0.705 ms per step -- and the median of five sat on the ramp.)
 
 The JSON line's `roofline` carries the fractions of the four resources a gather-and-compute kernel can be bound by and names as `bound`
 the largest of them -- whatever it is; `bound_by_probe` next to it says which resource the kernel RESPONDS to (round 4's probe builds of the
@@ -221,7 +223,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region (value = the median one)")
+    ap.add_argument("--reps", type=int, default=9, help="repetitions of the timed region (value = the median one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C4 leg of the `configs` block")
     ap.add_argument("--width", type=int, default=WIDTH)

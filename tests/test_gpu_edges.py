@@ -232,8 +232,8 @@ def test_bench_single_gpu_contract_line():
         assert k in rf, k
     assert rf["frames_per_launch"] == 12.0 and rf["launches"] == 1
     # the timed region is repeated; the line carries the median repetition and the spread
-    assert r["reps"] == 5 and len(r["ms_per_step_all"]) == 5 and r["ms_per_step_min_max"][0] <= r["ms_per_step"] <= r["ms_per_step_min_max"][1]
-    assert sorted(r["ms_per_step_all"])[2] == r["ms_per_step"]
+    assert r["reps"] == 9 and len(r["ms_per_step_all"]) == 9 and r["ms_per_step_min_max"][0] <= r["ms_per_step"] <= r["ms_per_step_min_max"][1]
+    assert sorted(r["ms_per_step_all"])[4] == r["ms_per_step"]
     # ... and is followed by a second or so of back-to-back launches that end on the verified frame, bit for bit
     assert r["sustained"]["last_frame_identical_to_verified"] is True and r["sustained"]["frames"] >= 256 and r["sustained"]["seconds"] >= 1.0
     assert set(rf["peak_source"]) == {"l1_gather_requests", "valu_issue", "l2_bandwidth", "hbm_fabric"}
