@@ -41,6 +41,40 @@ def test_megakernel_registers_scratch_and_occupancy_are_pinned():
         assert f["LDS Size [bytes/block]"] <= 160 * 1024 // 24, f                  # six single-wave workgroups per SIMD fit the CU's LDS
 
 
+@pytest.mark.skipif(HIPCC is None, reason="hipcc is missing")
+def test_the_step_waits_for_the_pieces_of_its_record_one_by_one(tmp_path):
+    """Round 5: the traversal step asks for the four 16-byte pieces of its record at once and waits for them piece by piece (node side first: child 3, 2, 1, 0).
+    That is a property of what the compiler emits -- load order and `s_waitcnt vmcnt(3..0)` placement --, not of the source alone: pinned here for the production
+    variant's two one-ray-per-lane instances of the loop."""
+    flags = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -enable-post-misched=false -fvisibility=hidden".split()
+    asm = tmp_path / "mk.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", *flags, "-I" + os.path.join(os.path.dirname(HERE), "include"),
+                    "-S", "--cuda-device-only", os.path.join(CSRC, "pt_megakernel.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=900)
+    text = asm.read_text()
+    start = text.index("_ZN3ptk18trace_paths_kernelILb0ELb1EEEvNS_10RenderArgsE:")
+    body = text[start:text.index("s_endpgm", start)]
+    lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+    groups = 0
+    for i in range(len(lines) - 4):
+        four = lines[i:i + 4]
+        if not all(l.startswith("global_load_dwordx4") for l in four):
+            continue
+        if [re.search(r"offset:(\d+)", l).group(1) if "offset:" in l else "0" for l in four] != ["48", "32", "16", "0"]:
+            continue
+        waits = []
+        for l in lines[i + 4:]:
+            if l.startswith("global_load") or l.startswith("global_store") or l.startswith("s_cbranch_execz .LBB") and len(waits) >= 4:
+                break
+            m = re.match(r"s_waitcnt vmcnt\((\d)\)$", l)
+            if m:
+                waits.append(int(m.group(1)))
+                if len(waits) == 4:
+                    break
+        assert waits == [3, 2, 1, 0], (i, waits)
+        groups += 1
+    assert groups == 2, groups            # the dense instance and the one that hands shadow rays to idle lanes
+
+
 LOADS = re.compile(r"\b(ds_read\w*|ds_load\w*|global_load\w*|buffer_load\w*|flat_load\w*|scratch_load\w*|s_load\w*|s_buffer_load\w*|global_atomic\w*|ds_\w*_rtn\w*)\b")
 
 
