@@ -272,10 +272,11 @@ bool root_box_rect(const pt::WideBvh& w, const ptk::FrameParams& f, uint32_t wid
 
 // May the launch use the short forms of the correctly rounded reciprocal and square root (pt_device.h::rcp_normal / sqrt_normal: bit-identical to the
 // IEEE operations for operands of magnitude 2^-64 ... 2^64, and for sqrt(0))?  Their operands, site by site:
-//   * 1 / det of the triangle test, det = e1 . (d x e2), so |det| <= |e1| |e2| |d|: every edge component is below 2^20 (edges_small: |e1| |e2| < 3 * 2^40) and
-//     no ray direction is longer than 2^20 -- shadow and bounce directions are unit vectors, a camera direction is a unit vector rotated by the frame's
-//     quaternion, scaled by |q|^2 when that is not of unit length (renderer.wgsl:66-72): every frame's |q|^2 has to stay below 2^20.  A det below
-//     the range fails the test's own |det| < 1e-7 and its quotient is never used;
+//   * 1 / det of the triangle test, det = e1 . (d x e2), so |det| <= |e1| |e2| |d|.  Every edge component is below 2^20 (edges_small: |e1| |e2| < 3 * 2^40).
+//     Shadow and bounce directions are unit vectors; a camera direction is a unit vector v taken through rotateVectorByQuat (renderer.wgsl:66-72),
+//     v + 2 (s u x v + u x (u x v)) with q = (u, s): |2 s u x v| <= |q|^2 and |2 u x (u x v)| <= 2 |q|^2, so |d| <= 1 + 3 |q|^2 -- NOT |q|^2.  With every
+//     frame's |q|^2 below 2^18 that is |d| < 2^19.6 and |det| < 2^61.2: 3.8 binades under the 2^65 the short forms are proven for (tools/probes/rcp_exact.hip).
+//     A det below the range fails the test's own |det| < 1e-7 and its quotient is never used;
 //   * the three reciprocals of a ray's direction: taken only for |component| > 1e-8 (safeInvDir), bounded above as just said;
 //   * normalize() of the camera-space direction (p.x * aspect, p.y, -focal) with |p| <= 1: its squared length lies in [focal^2, aspect^2 + 1 + focal^2],
 //     so focal and aspect have to be of ordinary magnitude (1e-6 ... 1e6 is asked here);
@@ -287,7 +288,7 @@ bool arith_is_bounded(const PtContext* ctx, const std::vector<ptk::FrameParams>&
     for (uint32_t i = 0; i < nf; ++i) {
         const float* q = frames[i].quat;
         const double n2 = double(q[0]) * q[0] + double(q[1]) * q[1] + double(q[2]) * q[2] + double(q[3]) * q[3];
-        if (!(n2 < 1048576.0)) return false;
+        if (!(n2 < 262144.0)) return false;                              // 2^18, see above
         if (!(frames[i].focal > 1e-6f && frames[i].focal < 1e6f && frames[i].aspect < 1e6f && frames[i].aspect > -1e6f)) return false;
     }
     return true;
@@ -1242,6 +1243,18 @@ int pt_read_accum(PtContext* ctx, float* dst, uint64_t dst_floats) {
     const DevBuf<float4>& acc = info.compact ? ctx->d_compact_accum : ctx->d_accum;
     PT_HIP(ctx, hipMemcpyAsync(dst, acc.ptr, info.floats * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // A compact dump is tile-major (tile slot * 64 + ly * 8 + lx); where the frame is not a multiple of 8 the edge tiles carry pixels outside the image
+    // that resolve_kernel never writes: zeroed here, so that two dumps of the same state are the same bytes.
+    if (info.compact && ((info.width | info.height) & 7u)) {
+        std::vector<uint32_t> tiles; pt::tile_list(info.width, info.height, info.tile_rank, info.tile_count ? info.tile_count : 1u, tiles);
+        const uint32_t tiles_x = (info.width + 7u) / 8u;
+        for (size_t slot = 0; slot < tiles.size(); ++slot) {
+            const uint32_t x0 = (tiles[slot] % tiles_x) * 8u, y0 = (tiles[slot] / tiles_x) * 8u;
+            if (x0 + 8u <= info.width && y0 + 8u <= info.height) continue;
+            for (uint32_t p = 0; p < 64u; ++p)
+                if (x0 + (p & 7u) >= info.width || y0 + (p >> 3) >= info.height) std::memset(dst + (slot * 64u + p) * 4u, 0, 4 * sizeof(float));
+        }
+    }
     return PT_OK;
 }
 
@@ -1256,9 +1269,16 @@ int pt_set_accum(PtContext* ctx, const PtAccumInfo* info, const float* src) {
     const uint64_t need = compact ? uint64_t(pt::tile_count_of(info->width, info->height, info->tile_rank, count)) * 256ull : uint64_t(info->width) * info->height * 4ull;
     if (info->floats != need) return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_accum: `floats` does not match the shape (whole frame: W*H*4; tile share: tiles*64*4)");
     DevBuf<float4>& acc = compact ? ctx->d_compact_accum : ctx->d_accum;
+    if (need == 0) {                                                // a share that owns no tile (more shares than tiles): nothing to restore, nothing to read
+        ctx->accum_w = info->width; ctx->accum_h = info->height; ctx->accum_rank = accum_share_key(info->tile_rank, count, compact); ctx->accum_count = info->samples;
+        return PT_OK;
+    }
     // every pixel's w is the number of samples summed into it (resolve_kernel divides by it) and it is the same for all: a dump whose `samples`
-    // disagrees with its own data (edited by hand, truncated) would give means and checkpoint metadata that contradict each other
-    if (src[3] != float(info->samples) || src[need - 1] != float(info->samples))
+    // disagrees with its own data (edited by hand, truncated) would give means and checkpoint metadata that contradict each other.  Checked on pixels that
+    // are inside the image whatever the resolution: the first pixel of the first and of the last tile of a compact dump (a tile's origin is always inside;
+    // its last pixel is not when width or height is not a multiple of 8), the first and last pixel of a whole frame.
+    const uint64_t last_w = compact ? need - 256u + 3u : need - 1u;
+    if (src[3] != float(info->samples) || src[last_w] != float(info->samples))
         return fail(ctx, PT_ERR_INVALID_ARG, "pt_set_accum: `samples` does not match the sample count stored in the data (w of the first / last pixel)");
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // nothing in flight still reads or writes the running sums
     everything_delivered(ctx);

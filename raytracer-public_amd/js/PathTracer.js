@@ -91,6 +91,15 @@ class PathTracer {
     this.options.bruteForce = true; this._hasBVH = true;
   }
 
+  // setScene for a scene whose BVH2 was built before (data/BVH2.bin, what src/main.js:27-46 dumps): upload the triangles, install the
+  // BVH2 through the reference's own route (collapseLBVH2ToBVH4, then the BVH4 the renderer traverses) -- no rebuild
+  async setSceneWithBVH2(scene, bvh2U32) {
+    if (!this.device) return;
+    this.trianglesData = scene.getTrianglesFloat32();
+    if (this.group) native().groupSetTriangles(this.group, this.trianglesData); else native().setTriangles(this.device, this.trianglesData);
+    this.setBVH2(bvh2U32);
+  }
+
   // install a prebuilt BVH (data/BVH2.bin or data/BVH4_wide.bin) instead of rebuilding
   setBVH2(bvh2U32) { if (this.group) native().groupSetBVH2(this.group, bvh2U32); else native().setBVH2(this.device, bvh2U32); this._hasBVH = true; }
   setBVH4(bvh4U32) { if (this.group) native().groupSetBVH4(this.group, bvh4U32); else native().setBVH4(this.device, bvh4U32); this._hasBVH = true; }

@@ -10,7 +10,17 @@
 //   * world matrix = parent world x local, scene traversal in DFS pre-order, a node's own mesh
 //     primitives before its children (Object3D.traverse order, Scene.js:53);
 //   * indexed primitives are expanded (toNonIndexed, Scene.js:59-60); each vertex goes through
-//     Vector3.applyMatrix4 including its perspective divide (Scene.js:69-85).
+//     Vector3.applyMatrix4 including its perspective divide (Scene.js:69-85);
+//   * triangle strips and fans become triangles in the vertex order of three's toTrianglesDrawMode (what GLTFLoader applies to
+//     modes 5 / 6), sparse accessors are resolved as GLTFLoader.loadAccessor does, `.gltf` JSON files bring their buffers as
+//     external files (relative to the .gltf) or data: URIs, a GLB may name further buffers next to its BIN chunk;
+//   * the reference reads the position attribute's RAW array (Scene.js:66-85: `pos.array`, not getX): integer positions
+//     (KHR_mesh_quantization) arrive as the integers, also when the accessor says `normalized` -- reproduced here.
+// All of the above is pinned bit for bit by running three's own GLTFLoader on the same files (tests/golden/gen_golden_glb.js ->
+// glb_golden.json, gltf_synth_golden.json).  One deliberate difference: a NON-indexed TRIANGLES primitive over an interleaved view
+// is read with its stride here; the reference reads the interleaved array as if it were tightly packed (geometry.clone() keeps the
+// InterleavedBufferAttribute, Scene.js:66 then indexes its .array by 3) and gets normals / UVs mixed into the positions.
+// Draco- and (required) meshopt-compressed files are refused loudly -- the reference's GLTFLoader has no decoder set either (Scene.js:6).
 // Node-12-safe CommonJS.
 "use strict";
 const fs = require("fs");
@@ -88,7 +98,7 @@ function applyMatrix4(v, e) {       // with perspective divide
   return [(e[0] * x + e[4] * y + e[8] * z + e[12]) * w, (e[1] * x + e[5] * y + e[9] * z + e[13]) * w, (e[2] * x + e[6] * y + e[10] * z + e[14]) * w];
 }
 
-// ---- GLB container + accessors --------------------------------------------------------------
+// ---- containers (GLB / .gltf), buffers, accessors ---------------------------------------------------------------------------------
 function parseGLB(buf) {
   if (buf.length < 20 || buf.readUInt32LE(0) !== 0x46546c67) throw new Error("not a GLB file (bad magic)");
   const version = buf.readUInt32LE(4);
@@ -106,32 +116,83 @@ function parseGLB(buf) {
   return { json: json, bin: bin };
 }
 
-const COMPONENT = { 5120: [1, "Int8"], 5121: [1, "UInt8"], 5122: [2, "Int16LE"], 5123: [2, "UInt16LE"], 5125: [4, "UInt32LE"], 5126: [4, "FloatLE"] };
-const TYPE_SIZE = { SCALAR: 1, VEC2: 2, VEC3: 3, VEC4: 4, MAT4: 16 };
+// GLTFLoader.parse: a file that starts with the magic "glTF" is the binary container, anything else is JSON text.
+// Buffers as GLTFParser.loadBuffer resolves them: no uri on buffer 0 = the GLB's BIN chunk; data: URIs decoded in place; anything
+// else is a path relative to the file (LoaderUtils.resolveURL; absolute paths stay).
+function parseFile(buf, baseDir) {
+  let gltf;
+  if (buf.length >= 4 && buf.toString("latin1", 0, 4) === "glTF") gltf = parseGLB(buf);
+  else {
+    let json;
+    try { json = JSON.parse(buf.toString("utf8")); } catch (e) { throw new Error("not a GLB file (bad magic) and not glTF JSON: " + e.message); }
+    gltf = { json: json, bin: null };
+  }
+  const json = gltf.json;
+  if (!json.asset || !(Number(json.asset.version) >= 2)) throw new Error("unsupported glTF asset version (2.0 or later is required)");
+  gltf.buffers = (json.buffers || []).map(function (def, i) {
+    if (def.uri === undefined) {
+      if (i === 0 && gltf.bin) return gltf.bin;
+      throw new Error("buffer " + i + " has no uri and is not the GLB's binary chunk");
+    }
+    const m = /^data:[^,]*?(;base64)?,(.*)$/.exec(def.uri);
+    if (m) return m[1] ? Buffer.from(m[2], "base64") : Buffer.from(decodeURIComponent(m[2]), "latin1");
+    if (/^(https?|blob):/i.test(def.uri)) throw new Error("buffer " + i + ": remote uris are not supported (" + def.uri.slice(0, 40) + ")");
+    const rel = decodeURIComponent(def.uri);
+    try { return fs.readFileSync(path.isAbsolute(rel) ? rel : path.join(baseDir || ".", rel)); }
+    catch (e) {      // the scene file IS there: its missing buffer is an unreadable scene, not an absent one (drivers fall back only on err.code === "ENOENT")
+      const err = new Error("buffer " + i + " (" + def.uri + ") cannot be read: " + e.message); err.code = "PT_GLTF_BUFFER"; throw err;
+    }
+  });
+  return gltf;
+}
 
+const COMPONENT = { 5120: [1, "Int8"], 5121: [1, "UInt8"], 5122: [2, "Int16LE"], 5123: [2, "UInt16LE"], 5125: [4, "UInt32LE"], 5126: [4, "FloatLE"] };
+const TYPE_SIZE = { SCALAR: 1, VEC2: 2, VEC3: 3, VEC4: 4, MAT2: 4, MAT3: 9, MAT4: 16 };
+
+function viewBytes(gltf, viewIndex, what) {
+  const view = (gltf.json.bufferViews || [])[viewIndex];
+  if (!view) throw new Error("missing bufferView " + viewIndex + " (" + what + ")");
+  const ext = view.extensions || {};
+  for (const name of ["EXT_meshopt_compression", "KHR_meshopt_compression"])
+    if (ext[name] && (gltf.json.extensionsRequired || []).indexOf(name) >= 0) throw new Error("meshopt-compressed buffer views are not supported (" + name + " is required by this file)");
+  const buffers = gltf.buffers || (gltf.bin ? [gltf.bin] : []);
+  const data = buffers[view.buffer || 0];
+  if (!data) throw new Error("bufferView " + viewIndex + " names buffer " + (view.buffer || 0) + ", which this file does not have");
+  return { data: data, offset: view.byteOffset || 0, stride: view.byteStride };
+}
+
+// GLTFParser.loadAccessor: the RAW component values (no `normalized` scaling: see the header), `count` elements of TYPE_SIZE
+// components; an accessor without a buffer view is zeros; `sparse` replaces the listed elements (values tightly packed).
 function readAccessor(gltf, index) {
-  const acc = gltf.json.accessors[index];
+  const acc = (gltf.json.accessors || [])[index];
   if (!acc) throw new Error("missing accessor " + index);
-  if (acc.sparse) throw new Error("sparse accessors are not supported");
   const comp = COMPONENT[acc.componentType];
   if (!comp) throw new Error("unsupported accessor component type " + acc.componentType);
   const n = TYPE_SIZE[acc.type], count = acc.count;
+  if (!n) throw new Error("unsupported accessor type " + acc.type);
   const out = new Array(count * n);
-  if (acc.bufferView === undefined) { for (let i = 0; i < out.length; i++) out[i] = 0; return { data: out, n: n, count: count }; }
-  const view = gltf.json.bufferViews[acc.bufferView];
-  if ((view.buffer || 0) !== 0 || !gltf.bin) throw new Error("only the embedded GLB buffer is supported");
-  const base = (view.byteOffset || 0) + (acc.byteOffset || 0);
-  const stride = view.byteStride || comp[0] * n;
   const rd = "read" + comp[1];
-  for (let i = 0; i < count; i++)
-    for (let k = 0; k < n; k++) {
-      let v = gltf.bin[rd](base + i * stride + k * comp[0]);
-      if (acc.normalized) {          // KHR_mesh_quantization-style normalised integers
-        if (acc.componentType === 5120) v = Math.max(v / 127, -1); else if (acc.componentType === 5121) v = v / 255;
-        else if (acc.componentType === 5122) v = Math.max(v / 32767, -1); else if (acc.componentType === 5123) v = v / 65535;
-      }
-      out[i * n + k] = v;
+  if (acc.bufferView === undefined) { for (let i = 0; i < out.length; i++) out[i] = 0; }
+  else {
+    const v = viewBytes(gltf, acc.bufferView, "accessor " + index);
+    const base = v.offset + (acc.byteOffset || 0);
+    const stride = v.stride || comp[0] * n;
+    if (count > 0 && base + (count - 1) * stride + comp[0] * n > v.data.length) throw new Error("accessor " + index + " reads beyond the end of its buffer");
+    for (let i = 0; i < count; i++)
+      for (let k = 0; k < n; k++) out[i * n + k] = v.data[rd](base + i * stride + k * comp[0]);
+  }
+  if (acc.sparse !== undefined) {
+    const sp = acc.sparse, icomp = COMPONENT[sp.indices.componentType];
+    if (!icomp || sp.indices.componentType === 5126) throw new Error("unsupported sparse index component type " + sp.indices.componentType);
+    const vi = viewBytes(gltf, sp.indices.bufferView, "sparse indices of accessor " + index);
+    const vv = viewBytes(gltf, sp.values.bufferView, "sparse values of accessor " + index);
+    const ib = vi.offset + (sp.indices.byteOffset || 0), vb = vv.offset + (sp.values.byteOffset || 0);
+    for (let i = 0; i < sp.count; i++) {
+      const at = vi.data["read" + icomp[1]](ib + i * icomp[0]);
+      if (at >= count) continue;                   // a typed-array store beyond the end is dropped (BufferAttribute.setX)
+      for (let k = 0; k < n; k++) out[at * n + k] = vv.data[rd](vb + (i * n + k) * comp[0]);
     }
+  }
   return { data: out, n: n, count: count };
 }
 
@@ -156,8 +217,8 @@ class Scene {
       if (fs.existsSync(alt)) file = alt;
     }
     let gltf;
-    try { gltf = parseGLB(fs.readFileSync(file)); }
-    catch (err) { console.error("GLB load failed:", err); throw err; }      // Scene.js:27-30
+    try { gltf = parseFile(fs.readFileSync(file), path.dirname(file)); }
+    catch (err) { console.error("GLB load failed:", err); throw err; }      // Scene.js:27-30 (a missing file keeps fs's err.code === "ENOENT")
     this.parseGLTF(gltf);
     if (this._normalizeEnabled) {
       console.log("Normalizing mesh (" + this._normalizeMode + ")...");
@@ -182,20 +243,29 @@ class Scene {
     }
     function emitPrimitive(prim, world) {
       const mode = prim.mode === undefined ? 4 : prim.mode;
+      if (mode > 6) throw new Error("THREE.GLTFLoader: Primitive mode unsupported: " + mode);     // what the reference's loader throws
+      if (prim.extensions && prim.extensions.KHR_draco_mesh_compression) throw new Error("Draco-compressed meshes are not supported (the reference's GLTFLoader has no DRACOLoader either)");
       if (mode < 4) return;                        // points / lines are not meshes (Scene.js:54)
-      if (mode !== 4) throw new Error("triangle strips / fans are not supported");
-      if (prim.extensions && prim.extensions.KHR_draco_mesh_compression) throw new Error("Draco-compressed meshes are not supported");
       if (prim.attributes.POSITION === undefined) return;
       const pos = readAccessor(gltf, prim.attributes.POSITION);
-      let order;
-      if (prim.indices !== undefined) order = readAccessor(gltf, prim.indices).data;
-      else { order = new Array(pos.count); for (let i = 0; i < pos.count; i++) order[i] = i; }
+      if (pos.n !== 3) throw new Error("POSITION accessor is not VEC3");
+      let index;
+      if (prim.indices !== undefined) index = readAccessor(gltf, prim.indices).data;
+      else { index = new Array(pos.count); for (let i = 0; i < pos.count; i++) index[i] = i; }
+      let order = index;
+      if (mode === 5 || mode === 6) {              // BufferGeometryUtils.toTrianglesDrawMode (GLTFLoader applies it to strips and fans)
+        order = [];
+        const nt = index.length - 2;
+        if (mode === 6) for (let i = 1; i <= nt; i++) order.push(index[0], index[i], index[i + 1]);
+        else for (let i = 0; i < nt; i++) { if (i % 2 === 0) order.push(index[i], index[i + 1], index[i + 2]); else order.push(index[i + 2], index[i + 1], index[i]); }
+      }
       const nTri = Math.floor(order.length / 3);
       for (let t = 0; t < nTri; t++) {
         const v = [];
         for (let k = 0; k < 3; k++) {
           const i = order[t * 3 + k];
-          // the position attribute is a Float32Array in three: values pass through f32
+          if (!(i < pos.count)) throw new Error("triangle index " + i + " is outside its POSITION accessor (" + pos.count + " vertices)");
+          // a float position attribute is a Float32Array in three: values pass through f32 (integers are exact either way)
           v.push(applyMatrix4([Math.fround(pos.data[i * 3]), Math.fround(pos.data[i * 3 + 1]), Math.fround(pos.data[i * 3 + 2])], world));
         }
         self.triangles.push({
@@ -259,4 +329,4 @@ class Scene {
   }
 }
 
-module.exports = { Scene, parseGLB };
+module.exports = { Scene, parseGLB, parseFile };

@@ -7,6 +7,11 @@
 //
 //   node tests/golden/gen_golden_glb.js [/root/reference]
 //
+// Second leg (round 6): the synthetic files of synth_gltf.js (strips, fans, sparse accessors, .gltf with external and data-URI
+// buffers, quantised positions, several scenes ...) go through the reference's path AS Scene.js:15-42 WALKS IT -- GLTFLoader.load(url),
+// i.e. FileLoader + fetch -- with browser-environment shims only (fetch / Request / Headers over fs and data: URIs; Node 12 has none),
+// then through the same extract / normalise statements -> gltf_synth_golden.json (bit patterns only).
+//
 // Runs from a scratch directory that symlinks the reference's node_modules (nothing is copied
 // into this repo except the two small .glb data files and the resulting numbers).
 "use strict";
@@ -19,6 +24,19 @@ fs.writeFileSync(path.join(scratch, "package.json"), '{"type":"module"}');
 fs.writeFileSync(path.join(scratch, "run.js"), `
 globalThis.self = globalThis;
 if (typeof AbortController === "undefined") globalThis.AbortController = class { constructor() { this.signal = {}; } abort() {} };
+// browser environment for FileLoader (three.core.js: fetch(new Request(url, {headers: new Headers(...), signal})), then response.arrayBuffer() / .text())
+globalThis.AbortSignal = globalThis.AbortSignal || {};
+globalThis.Headers = globalThis.Headers || class { constructor(h) { this.h = h || {}; } get(k) { return this.h[k] || null; } };
+globalThis.Request = globalThis.Request || class { constructor(url) { this.url = url; } };
+globalThis.fetch = globalThis.fetch || (async (req) => {
+  const url = typeof req === "string" ? req : req.url;
+  let buf;
+  const m = /^data:[^,]*?(;base64)?,(.*)$/.exec(url);
+  if (m) buf = m[1] ? Buffer.from(m[2], "base64") : Buffer.from(decodeURIComponent(m[2]), "utf8");
+  else { try { buf = fs.readFileSync(url); } catch (e) { return { status: 404, statusText: "Not Found", url: url, headers: new Headers() }; } }
+  const ab = buf.buffer.slice(buf.byteOffset, buf.byteOffset + buf.byteLength);
+  return { status: 200, url: url, headers: new Headers(), arrayBuffer: async () => ab, text: async () => buf.toString("utf8"), json: async () => JSON.parse(buf.toString("utf8")) };
+});
 import * as THREE from "three";
 import { GLTFLoader } from "three/examples/jsm/loaders/GLTFLoader.js";
 import fs from "fs";
@@ -50,6 +68,19 @@ function normalize(tris, mode) {   // Scene.js:104-165
 }
 function f32(tris) { const a = new Float32Array(tris.length * 9); let o = 0; for (const t of tris) for (const v of [t.v0, t.v1, t.v2]) for (let k = 0; k < 3; k++) a[o++] = v[k]; return a; }
 const bits = (a) => Array.from(new Uint32Array(a.buffer));
+const synth = JSON.parse(process.argv[4] || "[]");
+if (synth.length) {        // second leg: loader.load(url) as Scene.js:19-32
+  const sout = {}; let left = synth.length;
+  const warn = console.warn; console.warn = () => {};           // toNonIndexed on zero-triangle strips etc.
+  for (const f of synth) {
+    new GLTFLoader().load(f, (gltf) => {
+      const raw = extract(gltf); const rawF32 = f32(raw);
+      normalize(raw, "cube");
+      sout[f.split("/").pop()] = { numTris: rawF32.length / 9, world_f32_bits: bits(rawF32), normalized_cube_f32_bits: bits(f32(raw)) };
+      if (--left === 0) { console.warn = warn; fs.writeFileSync(process.argv[5], JSON.stringify(sout)); }
+    }, undefined, (e) => { console.error("load failed", f, e); process.exit(1); });
+  }
+}
 let pending = files.length;
 for (const f of files) {
   const buf = fs.readFileSync(f); const ab = buf.buffer.slice(buf.byteOffset, buf.byteOffset + buf.byteLength);
@@ -63,11 +94,17 @@ for (const f of files) {
 }
 `);
 const files = ["dodecahedron.glb", "steve.glb"].map((f) => path.join(REF, "public/assets", f));
+const OUT2 = path.join(__dirname, "gltf_synth_golden.json");
+const synthDir = fs.mkdtempSync(path.join(os.tmpdir(), "ptsynth-"));
+const synth = require("./synth_gltf.js").writeAll(synthDir).map((f) => path.join(synthDir, f));
 try {
-  cp.execFileSync(process.execPath, [path.join(scratch, "run.js"), JSON.stringify(files), OUT], { stdio: "inherit", cwd: scratch });
+  cp.execFileSync(process.execPath, [path.join(scratch, "run.js"), JSON.stringify(files), OUT, JSON.stringify(synth), OUT2], { stdio: "inherit", cwd: scratch });
   console.log("wrote", OUT, fs.statSync(OUT).size, "bytes");
+  console.log("wrote", OUT2, fs.statSync(OUT2).size, "bytes");
   for (const f of files) fs.copyFileSync(f, path.join(__dirname, path.basename(f)));   // the .glb inputs are data fixtures
 } finally {
+  for (const f of fs.readdirSync(synthDir)) fs.unlinkSync(path.join(synthDir, f));
+  fs.rmdirSync(synthDir);
   for (const f of fs.readdirSync(scratch)) { const p = path.join(scratch, f); if (fs.lstatSync(p).isSymbolicLink()) fs.unlinkSync(p); else fs.unlinkSync(p); }
   fs.rmdirSync(scratch);
 }

@@ -1,0 +1,122 @@
+"""BASELINE's C4 and C2 through the ingest their wording names, at full size, through the Node boundary (VERDICT r5 "next" 1):
+
+  C4  "Sponza GLB (~260k tris) via loadGLB(), 1920x1080, 4 spp, 8 bounces": a realistic 262,144-triangle GLB (tests/glb_writer.py: several meshes
+      and primitives, TRS + matrix nodes, u16 and u32 index buffers, interleaved views) -> `node js/main.mjs --glb ...` = Scene.loadGLB
+      (normalize: true, mode "cube", src/main.js:20-23) -> setScene -> BVH2 dump -> render.  The triangles the loader produced equal the independent
+      numpy glTF rules' (f32 rounding), data/BVH2.bin equals the oracle's LBVH2 of them word for word, and the frame equals the oracle's on every pixel.
+  C2  "Stanford Dragon (data/BVH2.bin)": the 871,414-triangle run's data/BVH2.bin, loaded by a FRESH process through setBVH2 (file -> collapse ->
+      render), gives the build path's frame bit for bit (and the oracle's on a pixel grid).
+
+Plus the failure behaviour of the drivers: a GLB that exists and cannot be read ends the process non-zero; only an absent one falls back."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import orc as orc_mod
+from scenes import quat_yaw_pitch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+NODE = shutil.which("node")
+MAIN_MJS = os.path.join(ROOT, "raytracer-public_amd", "js", "main.mjs")
+MAIN_JS = os.path.join(ROOT, "raytracer-public_amd", "js", "main.js")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(NODE is None, reason="node is not installed")]
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def run_node(args, cwd, timeout=600):
+    r = subprocess.run([NODE] + args, capture_output=True, text=True, timeout=timeout, cwd=cwd)
+    return r.returncode, r.stdout, r.stderr
+
+
+def test_c4_sponza_class_glb_through_loadglb_full_size(tmp_path, rt, orc):
+    from glb_writer import write_realistic_glb, normalize_cube
+    n = 262144
+    soup = rt.procedural_scene(rt.SCENE_SPONZA_CLASS, n)
+    glb = str(tmp_path / "sponza_class.glb")
+    expect, stats = write_realistic_glb(glb, soup, seed=4)
+    assert stats["u16"] >= 2 and stats["u32"] >= 1 and stats["interleaved"] >= 2 and stats["nonindexed"] == 1
+    want_tris, center, scale = normalize_cube(expect)                 # what loadGLB(..., {normalize: true, mode: "cube"}) must hand to setScene
+    cam = tuple(float(np.float32(v)) for v in (np.array([0.55, -0.05, 0.05]) - center) * scale)      # the C4 camera, moved with the mesh
+    quat = tuple(float(np.float32(v)) for v in quat_yaw_pitch(1.45, 0.05))
+    w, h = 1920, 1080
+    rc, out, err = run_node([MAIN_MJS, "--glb", glb, "--mode", "2", "--spp", "4", "--bounces", "8", "--seed", "3", "--frames", "1", "--width", str(w), "--height", str(h),
+                             "--cam", ",".join(repr(v) for v in cam), "--quat", ",".join(repr(v) for v in quat),
+                             "--dump", str(tmp_path / "data" / "BVH2.bin"), "--radiance", str(tmp_path / "img.f32"), "--triangles", str(tmp_path / "tris.f32")], str(tmp_path))
+    assert rc == 0, err
+    m = re.search(r"Loaded .* -> (\d+) triangles in (\d+) ms", out)
+    assert m and int(m.group(1)) == n, out
+    print("Scene.loadGLB: %d triangles (%d-byte GLB) in %s ms" % (n, os.path.getsize(glb), m.group(2)))
+    tris = np.fromfile(str(tmp_path / "tris.f32"), np.float32)
+    assert tris.size == n * 9
+    assert np.allclose(tris.reshape(-1, 3, 3), want_tris.astype(np.float32), rtol=2e-6, atol=2e-6)
+    # data/BVH2.bin is the oracle's LBVH2 of those triangles, word for word
+    morton, tri_index = rt.morton_sort(tris)
+    bvh2 = np.fromfile(str(tmp_path / "data" / "BVH2.bin"), np.uint32)
+    assert np.array_equal(bvh2, orc.build_lbvh2(tris, morton, tri_index))
+    bvh4, _ = orc.collapse_bvh4(bvh2, n)
+    # the frame main.mjs rendered last (setFrameCount(1)): every pixel against the oracle
+    ref, ost = orc.render_mt(orc.make_params(w, h, n, cam, quat, mode=orc_mod.MODE_PATH, spp=4, max_bounces=8, seed=3, frame=1), tris, bvh4)
+    img = np.fromfile(str(tmp_path / "img.f32"), np.float32).reshape(h, w, 4)
+    assert same_bits(img, ref)
+    assert ost["rays_closest"] > 4 * ost["samples"]                   # an interior: long paths, nearly every camera ray hits
+
+
+def test_c2_bvh2_bin_reloaded_by_a_fresh_process(tmp_path, rt, orc):
+    n = 871414
+    w, h = 1920, 1080
+    common = ["--mode", "2", "--spp", "4", "--bounces", "8", "--seed", "1", "--frames", "2", "--width", str(w), "--height", str(h)]
+    dump = str(tmp_path / "data" / "BVH2.bin")
+    # run 1: the driver's own sequence (no dragon.glb: the procedural stand-in of the same triangle budget), data/BVH2.bin written, frame kept
+    rc, out, err = run_node([MAIN_MJS] + common + ["--dump", dump, "--radiance", str(tmp_path / "built.f32"), "--triangles", str(tmp_path / "tris.f32")], str(tmp_path))
+    assert rc == 0, err
+    assert "GLB not available" in out and "BVH2 dump complete" in out
+    assert os.path.getsize(dump) == 4 * (1 + 6 * (2 * n - 1))          # PathTracer.js:227: 1 + 6 (2N - 1) words
+    # run 2: a fresh process installs the FILE through setBVH2 (collapse, then the renderer's BVH4) instead of building
+    t0 = time.time()
+    rc, out2, err = run_node([MAIN_MJS] + common + ["--bvh2", dump, "--dump", str(tmp_path / "again" / "BVH2.bin"), "--radiance", str(tmp_path / "loaded.f32")], str(tmp_path))
+    assert rc == 0, err
+    assert "Installed prebuilt BVH2" in out2 and "BVH Build Time" not in out2
+    print("fresh process, data/BVH2.bin -> setBVH2 -> 2 frames: %.1f s wall" % (time.time() - t0))
+    built = np.fromfile(str(tmp_path / "built.f32"), np.float32).reshape(h, w, 4)
+    loaded = np.fromfile(str(tmp_path / "loaded.f32"), np.float32).reshape(h, w, 4)
+    assert same_bits(built, loaded)
+    # the file survives the round trip through the second process unchanged (readBVH2 after setBVH2)
+    assert open(dump, "rb").read() == open(str(tmp_path / "again" / "BVH2.bin"), "rb").read()
+    # and both are the oracle's frame (every 4th pixel in x and y, all samples) over the BVH4 collapsed from the FILE
+    tris = np.fromfile(str(tmp_path / "tris.f32"), np.float32)
+    bvh4, _ = orc.collapse_bvh4(np.fromfile(dump, np.uint32), n)
+    ref, _, _ = orc.render(orc.make_params(w, h, n, mode=orc_mod.MODE_PATH, spp=4, max_bounces=8, seed=1, frame=2, step=(4, 4)), tris, bvh4)
+    assert same_bits(loaded[::4, ::4], ref[::4, ::4])
+
+
+@pytest.mark.parametrize("driver", [MAIN_MJS, MAIN_JS])
+def test_unreadable_glb_stops_the_driver_absent_glb_falls_back(tmp_path, driver):
+    """src/main.js:20-23 has no catch and Scene.js:27-30 rejects: a GLB that cannot be read ends the app.  Here too -- non-zero status, the loader's
+    message, no frame rendered; a file that is simply not there is the one case that falls back to the stand-in."""
+    bad = tmp_path / "broken.glb"
+    bad.write_bytes(b"glTF\x02\x00\x00\x00" + b"\x00" * 40)
+    small = ["--width", "160", "--height", "96", "--frames", "2", "--tris", "5000", "--dump", str(tmp_path / "d" / "BVH2.bin")]
+    rc, out, err = run_node([driver, "--glb", str(bad)] + small, str(tmp_path), timeout=120)
+    assert rc != 0 and "GLB" in err and "FPS" not in out and "stand-in" not in out
+    rc, out, err = run_node([driver, "--glb", str(tmp_path / "absent.glb")] + small, str(tmp_path), timeout=120)
+    assert rc == 0, err
+    assert "GLB not available" in out and "FPS" in out
+    # a .gltf whose external buffer is missing is an unreadable file, not an absent one ... its error is ENOENT too, but for ANOTHER path:
+    # the stand-in must not silently replace a scene whose .gltf is there
+    import json
+    gltf = tmp_path / "scene.gltf"
+    gltf.write_text(json.dumps({"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}], "meshes": [{"primitives": [{"attributes": {"POSITION": 0}}]}],
+                                "buffers": [{"byteLength": 36, "uri": "gone.bin"}], "bufferViews": [{"buffer": 0, "byteLength": 36}],
+                                "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}]}))
+    rc, out, err = run_node([driver, "--glb", str(gltf)] + small, str(tmp_path), timeout=120)
+    assert rc != 0 and "stand-in" not in out

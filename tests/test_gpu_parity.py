@@ -303,6 +303,62 @@ def test_accumulation_checkpoint_resumes_bit_for_bit(rt, orc, gpu_ctx):
         fresh.close()
 
 
+@pytest.mark.parametrize("w,h", [(100, 60), (97, 64), (104, 61)])
+def test_accumulation_checkpoint_at_ragged_resolutions(rt, gpu_ctx, w, h):
+    """Checkpoints where width or height is not a multiple of 8: the edge tiles of a compact (tile-major) dump carry pixels outside the image that
+    no kernel writes -- the dump zeroes them (two dumps of one state are the same bytes) and pt_set_accum validates the sample count on pixels
+    inside the image.  Whole-frame COMPACT dump, a 1/3 share, and a share that owns no tile at all (more shares than tiles)."""
+    tris = rt.procedural_scene(0, 8000)
+    gpu_ctx.set_triangles(tris); gpu_ctx.build_bvh()
+    fresh = rt.Context(0)
+    try:
+        fresh.set_triangles(tris); fresh.build_bvh()
+        spp = 2
+        for share in (dict(flags=rt.PT_FLAG_COMPACT), dict(tile_rank=1, tile_count=3), dict(tile_rank=2, tile_count=3)):
+            flags = share.pop("flags", 0)
+            def params(ctx, f):
+                p = ctx.make_params(w, h, frame=f, mode=rt.PT_MODE_PATH, spp=spp, max_bounces=3, seed=5, accumulate=True, **share)
+                p.flags |= flags
+                return p
+            for f in range(3):
+                gpu_ctx.render(params(gpu_ctx, f))
+            gpu_ctx.synchronize()
+            info, dump = gpu_ctx.read_accum()
+            rank, count = share.get("tile_rank", 0), share.get("tile_count", 1)
+            ids = rt.tile_ids(w, h, rank, count)
+            assert info.compact == 1 and info.samples == 3 * spp and info.floats == len(ids) * 256
+            d = dump.reshape(len(ids), 8, 8, 4)
+            tiles_x = (w + 7) // 8
+            inside = np.zeros((len(ids), 8, 8), bool)
+            for s, t in enumerate(ids):
+                x0, y0 = (int(t) % tiles_x) * 8, (int(t) // tiles_x) * 8
+                inside[s] = ((y0 + np.arange(8))[:, None] < h) & ((x0 + np.arange(8))[None, :] < w)
+            assert not inside.all()                                             # the case under test: some edge tile sticks out
+            assert np.all(d[inside][:, 3] == np.float32(3 * spp)) and np.all(d[~inside] == 0)
+            _, again = gpu_ctx.read_accum()
+            assert same_bits(again, dump)
+            for f in range(3, 5):
+                gpu_ctx.render(params(gpu_ctx, f))
+            gpu_ctx.synchronize()
+            _, want = gpu_ctx.read_accum()
+            fresh.set_accum(info, dump)                                         # was refused: the last float of the dump is outside the image
+            for f in range(3, 5):
+                fresh.render(params(fresh, f))
+            fresh.synchronize()
+            _, got = fresh.read_accum()
+            assert same_bits(got, want)
+            bad = dump.copy(); bad[(len(ids) - 1) * 256 + 3] = np.float32(1)    # the last tile's first pixel IS inside: still validated
+            with pytest.raises(rt.PtError):
+                fresh.set_accum(info, bad)
+        # a share with no tile: 4095 shares of a 13 x 8-tile frame, rank 4000 -- zero floats, accepted without touching the (empty) array
+        empty = rt.PtAccumInfo(); empty.width, empty.height, empty.tile_rank, empty.tile_count, empty.compact, empty.samples, empty.floats = w, h, 4000, 4095, 1, 4, 0
+        assert len(rt.tile_ids(w, h, 4000, 4095)) == 0
+        fresh.set_accum(empty, np.zeros(0, np.float32))
+        assert fresh.accum_info().samples == 4 and fresh.accum_info().floats == 0
+    finally:
+        fresh.close()
+
+
 def test_sponza_class_interior_bit_exact(rt, orc, gpu_ctx):
     # config C4 in miniature: camera inside, every ray hits, long thin triangles -> deep LBVH
     tris = rt.procedural_scene(1, 30000)
@@ -356,6 +412,29 @@ def test_short_reciprocal_forms_bit_exact(rt, gpu_ctx, orc):
     assert int(dbg[7]) & 1 == 0                                    # the general variant, chosen by the host
     assert same_bits(img, ref)
     assert (img[..., 0] != np.float32(0.01)).any()                 # the frame is not empty
+    # just INSIDE the gate, worst case for 1 / det: coordinates near the top of what f16 boxes can bound (|x| <= 3e4, edge components up to 6e4)
+    # and |q|^2 = 260,100 < 2^18, so camera directions are up to 1 + 3 |q|^2 = 7.8e5 long -- the host must pick the short forms by itself
+    # and they must still be the oracle's IEEE quotients bit for bit
+    rng = np.random.default_rng(77)
+    big_tris = rng.uniform(-3e4, 3e4, (1500, 3, 3)).astype(np.float32).reshape(-1)
+    gpu_ctx.set_triangles(big_tris); gpu_ctx.build_bvh()
+    bvh4b = gpu_ctx.read_bvh4()
+    q510 = tuple(510.0 * c for c in quat_yaw_pitch(0.7, -0.3))
+    cam0 = (100.0, -50.0, 25.0)
+    op = orc.make_params(w, h, big_tris.size // 9, cam0, q510, mode=orc_mod.MODE_PATH, spp=2, max_bounces=4, seed=5, frame=1)
+    ref, _, ost = orc.render(op, big_tris, bvh4b)
+    gpu_ctx.render(gpu_ctx.make_params(w, h, cam0, q510, mode=rt.PT_MODE_PATH, spp=2, max_bounces=4, seed=5, frame=1, stats=True))
+    img = gpu_ctx.read_radiance(); st = gpu_ctx.stats()
+    rt.lib.pt_debug_counters(gpu_ctx.h, dbg.ctypes.data_as(C.c_void_p))
+    assert int(dbg[7]) & 1 == 1                                    # the short forms, chosen by the host
+    assert same_bits(img, ref)
+    assert st["tris_tested"] == ost["tris_tested"] > 10000 and st["nodes_examined"] == ost["nodes_examined"]
+    # and just outside (|q|^2 = 2^18 exactly): the general variant
+    q512 = tuple(512.0 * c for c in (0.0, 0.0, 0.0, 1.0))
+    gpu_ctx.render(gpu_ctx.make_params(w, h, cam0, q512, mode=rt.PT_MODE_PATH, spp=1, max_bounces=1, seed=5, stats=True))
+    gpu_ctx.synchronize()
+    rt.lib.pt_debug_counters(gpu_ctx.h, dbg.ctypes.data_as(C.c_void_p))
+    assert int(dbg[7]) & 1 == 0
 
 
 def test_quad_mode_drain_bit_exact(rt, gpu_ctx, orc):
