@@ -207,6 +207,85 @@ def busy_ms(starts, durs):
     return total
 
 
+COLLECTIVE_TIMEOUT_S = float(os.environ.get("PT_BENCH_TIMEOUT", "120"))     # every collective (and the rendezvous) gives up after this long: well under the driver's 600 s limit
+
+
+def init_distributed(dist, backend, rank, world, device=None, init_method=None):
+    """The process group of a sharded run, with a timeout on every collective: a rank that never arrives (died, hung) makes the others raise after
+    COLLECTIVE_TIMEOUT_S instead of sitting in dist.gather until somebody kills the job (torch's default is 10 minutes -- the driver's whole limit)."""
+    from datetime import timedelta
+    kw = dict(backend=backend, rank=rank, world_size=world, timeout=timedelta(seconds=COLLECTIVE_TIMEOUT_S))
+    if init_method:
+        kw["init_method"] = init_method
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(**kw)
+
+
+def abort_rank(dist, rank, exc, code=4):
+    """A rank that raised after the process group came up: say what happened, take the group down best-effort (a watchdog ends the process if
+    the teardown itself blocks on a collective the dead peer will never join), and EXIT non-zero -- a plain exit, never an exec.  Under
+    torch.distributed.run the agent then stops the other ranks at once; started any other way they run into the collective timeout above."""
+    import threading, traceback
+    print("bench.py: rank %d failed: %s" % (rank, "".join(traceback.format_exception(type(exc), exc, exc.__traceback__)).rstrip()), file=sys.stderr, flush=True)
+    threading.Timer(10.0, lambda: os._exit(code)).start()
+    try:
+        if dist is not None and dist.is_initialized():
+            dist.destroy_process_group()
+    except BaseException:
+        pass
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(code)
+
+
+class GatherPipeline:
+    """The collective side of a sharded run: launch b's packed shares are gathered to rank 0 while launch b+1 traces; `finish` of launch b-1 runs
+    after launch b has been submitted.  One instance per run; bench.py and tests/test_bench_multirank_gloo.py (8 gloo ranks, CPU tensors) both drive it.
+
+    packed[slot]   [batch, floats] this rank's shares of the launch in flight in `slot` (two slots, used alternately)
+    gathered[slot] rank 0: [world, batch, floats]; None elsewhere
+    on_finish(slot, nf): rank 0, after the gather of a launch has landed (bench.py: pt_unpack_batch into the frames)
+    host_stage: gather through host memory, synchronously (gloo rehearsals); before_host_copy() makes the producer's work visible first"""
+
+    def __init__(self, dist, torch, rank, world, packed, gathered, on_finish, host_stage=False, before_host_copy=None):
+        self.dist, self.torch, self.rank, self.world = dist, torch, rank, world
+        self.packed, self.gathered, self.on_finish = packed, gathered, on_finish
+        self.host_stage, self.before_host_copy = host_stage, before_host_copy
+        self.pending = None
+        self.gathers = 0
+
+    def _host_gather(self, buf):
+        if self.before_host_copy:
+            self.before_host_copy()
+        src = buf.cpu()
+        lst = [self.torch.empty_like(src) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(src, lst, dst=0)
+        return lst
+
+    def ship(self, slot, nf):
+        """Launch in packed[slot][:nf] has been submitted (and packed): start its gather, then finish the previous launch's."""
+        if self.host_stage:
+            work = ("host", self._host_gather(self.packed[slot][:nf]))
+        else:
+            glist = [self.gathered[slot][r][:nf] for r in range(self.world)] if self.rank == 0 else None
+            work = ("async", self.dist.gather(self.packed[slot][:nf], glist, dst=0, async_op=True))
+        self.gathers += 1
+        self.finish()                      # gather(b-1) has had the whole launch b to complete
+        self.pending = (work, slot, nf)
+
+    def finish(self):
+        if self.pending is None:
+            return
+        (kind, work), slot, nf = self.pending
+        self.pending = None
+        if kind == "async":
+            work.wait()
+        elif self.rank == 0:
+            self.gathered[slot][:, :nf].copy_(self.torch.stack(work))
+        if self.rank == 0:
+            self.on_finish(slot, nf)
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as children of a process that has not
     touched the GPU (no exec of an initialised process) and hand their exit status on."""
@@ -253,10 +332,18 @@ def main():
     device = local_rank % max(n_dev, 1)
     torch.cuda.set_device(device)
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        init_distributed(dist, backend, rank, world, device=torch.device("cuda", device))
+    try:
+        run_bench(args, rank, world, device, backend, torch, dist, np, rt)
+    except SystemExit:
+        raise
+    except BaseException as exc:             # a rank that fails after the rendezvous must not leave the others waiting in a collective
+        if world > 1:
+            abort_rank(dist, rank, exc)
+        raise
+
+
+def run_bench(args, rank, world, device, backend, torch, dist, np, rt):
 
     width, height = args.width, args.height
     tris = rt.procedural_scene(rt.SCENE_DRAGON_CLASS, NUM_TRIS, SCENE_SEED)
@@ -330,41 +417,19 @@ def main():
     my_bytes = float(sum(frame_bytes)) / max(len(frame_bytes), 1)       # mean per frame
     ctx.set_batch(batch)
 
-    pending = [None]
     last_frame = {}                  # where the last timed frame ended up (whole-frame runs)
-
-    def finish(prev):
-        if prev is None:
-            return
-        work, slot, nf = prev
-        work.wait()
-        if rank == 0:
-            if host_stage:
-                gathered[slot][:, :nf].copy_(torch.stack(work.cpu_list))
-            # rank r's packed share of frame j sits at gathered[slot][r][j]: all nf frames are rebuilt by ONE launch, each into its own row-major frame
+    fail_at = tuple(int(x) for x in os.environ["PT_BENCH_FAIL"].split(":")) if os.environ.get("PT_BENCH_FAIL") else None
+    pipe = None
+    if sharded:
+        def unpack(slot, nf):            # rank r's packed share of frame j sits at gathered[slot][r][j]: all nf frames are rebuilt by ONE launch, each into its own row-major frame
             ctx.unpack_batch(gathered[slot].data_ptr(), batch * max(pstride, 4), max(pstride, 4), nf, width, height, world, rect, SPP, frames_full.data_ptr(), height * width * 4)
             last_frame["buf"] = nf - 1
-
-    class _HostWork:                 # gloo rehearsal: synchronous host gather
-        def __init__(self, buf):
-            stream.synchronize()
-            src = buf.cpu()
-            self.cpu_list = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
-            dist.gather(src, self.cpu_list, dst=0)
-
-        def wait(self):
-            pass
+        pipe = GatherPipeline(dist, torch, rank, world, packed, gathered, unpack, host_stage=host_stage, before_host_copy=stream.synchronize)
 
     def ship(slot, nf):              # the launch in compact[slot][:nf] has been submitted: pack it behind its resolve, gather it, finish the previous one
         if pstride:
             ctx.pack_shares(compact[slot].data_ptr(), stride, nf, width, height, rank, world, rect, packed[slot].data_ptr(), max(pstride, 4))
-        if host_stage:
-            work = _HostWork(packed[slot][:nf])
-        else:
-            glist = [gathered[slot][r][:nf] for r in range(world)] if rank == 0 else None
-            work = dist.gather(packed[slot][:nf], glist, dst=0, async_op=True)
-        finish(pending[0])               # gather(b-1) has had the whole launch b to complete
-        pending[0] = (work, slot, nf)
+        pipe.ship(slot, nf)
 
     def run(n_steps, first_frame, p, tag):    # called with `stream` current: n_steps frames as the launches of schedule()
         def set_target(k, j, frame):
@@ -376,13 +441,14 @@ def main():
 
         def after_launch(k, nf):
             launch_log.append((tag, nf))
+            if fail_at and tag == "timed" and (rank, k) == fail_at:      # PT_BENCH_FAIL="rank:launch" (tests): this rank dies in the middle of the timed region
+                raise RuntimeError("injected failure (PT_BENCH_FAIL) on rank %d at launch %d" % (rank, k))
             if sharded:
                 ship(k & 1, nf)
 
         submit_launches(ctx, p, schedule(n_steps, batch, world, fixed_batch), first_frame, batch, set_target, after_launch)
         if sharded:
-            finish(pending[0])
-            pending[0] = None
+            pipe.finish()
 
     p = params()
     with torch.cuda.stream(stream):

@@ -189,8 +189,14 @@ struct Lbvh2Ctx {
     }
 };
 
-inline float fmin3v(float a, float b, float c) { float m = (b < a) ? b : a; return (c < m) ? c : m; }
-inline float fmax3v(float a, float b, float c) { float m = (b > a) ? b : a; return (c > m) ? c : m; }
+// WGSL leaves min / max of (-0, +0) to the implementation; in the builder the choice is visible, because incrementF16 (BVHBuilder.wgsl:63-82) steps
+// -0 up to +0 but +0 up to the smallest subnormal.  Pinned: -0 orders below +0 (IEEE 754-2019 minimum / maximum) -- what the GPUs' min / max
+// instructions do (gfx950 v_min_f32 / v_max_f32 included), and what JS Math.min / Math.max do in the collapse (:644-645).  Found by
+// tests/test_gpu_ingest.py: a mesh centred by normalizeMesh has vertices at +-1e-9 on both sides of 0.
+inline float min_oz(float a, float b) { if (a < b) return a; if (b < a) return b; return std::signbit(a) ? a : b; }
+inline float max_oz(float a, float b) { if (a > b) return a; if (b > a) return b; return std::signbit(a) ? b : a; }
+inline float fmin3v(float a, float b, float c) { return min_oz(min_oz(a, b), c); }
+inline float fmax3v(float a, float b, float c) { return max_oz(max_oz(a, b), c); }
 
 void write_bounds2(uint32_t* bvh2, uint32_t node, const float mn[3], const float mx[3]) {
     // BVHBuilder.wgsl:83-102: widen by one f16 ULP outward in every component, then pack.
@@ -269,7 +275,7 @@ void build_lbvh2(const float* tris, uint32_t numTris, const uint32_t* morton,
             float lmn[3], lmx[3], rmn[3], rmx[3], umn[3], umx[3];
             read_bounds2(bvh2, bvh2[pBase + 3], lmn, lmx);
             read_bounds2(bvh2, bvh2[pBase + 4], rmn, rmx);
-            for (int k = 0; k < 3; k++) { umn[k] = (rmn[k] < lmn[k]) ? rmn[k] : lmn[k]; umx[k] = (rmx[k] > lmx[k]) ? rmx[k] : lmx[k]; }
+            for (int k = 0; k < 3; k++) { umn[k] = min_oz(lmn[k], rmn[k]); umx[k] = max_oz(lmx[k], rmx[k]); }
             write_bounds2(bvh2, p, umn, umx);
             node = p;
         }

@@ -48,6 +48,8 @@ template <bool B> __device__ __forceinline__ float sqrt_f(float x) { if constexp
 template <bool B = false> __device__ __forceinline__ F3 normalize3(F3 v) { const float inv = rcp_f<B>(sqrt_f<B>(dot3(v, v))); return v * inv; }
 // WGSL min/max on non-NaN data (sign of zero never reaches a comparison result)
 // -> v_min_f32 / v_max_f32 / v_min3_f32 / v_max3_f32
+// v_min_f32 / v_max_f32: -0 orders below +0 (the ISA's pseudo-code names the two zero cases).  In the slab test the sign of a zero never reaches a
+// comparison; in the LBVH2 builder it does (incrementF16 steps -0 and +0 differently), and the oracle's builder pins the same order (min_oz / max_oz).
 __device__ __forceinline__ float wmin(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float wmax(float a, float b) { return __builtin_fmaxf(a, b); }
 

@@ -212,7 +212,11 @@ int pt_group_create(const int* device_ordinals, uint32_t num_devices, uint32_t t
     g->n = num_devices; g->transport = transport;
     for (uint32_t r = 0; r < num_devices; ++r) {
         const int d = device_ordinals ? device_ordinals[r] : int(r);
-        if (d < 0 || d >= have) { delete g; return gfail(nullptr, PT_ERR_INVALID_ARG, "pt_group_create: device ordinal out of range"); }
+        if (d < 0 || d >= have) {
+            delete g;
+            return gfail(nullptr, PT_ERR_INVALID_ARG, "pt_group_create: device ordinal " + std::to_string(d) + " out of range (member " + std::to_string(r) + " of " + std::to_string(num_devices) +
+                                                      "; this process sees " + std::to_string(have) + " HIP device" + (have == 1 ? "" : "s") + ")");
+        }
         g->devices.push_back(d);
     }
     if (transport == PT_GROUP_TRANSPORT_RCCL) {

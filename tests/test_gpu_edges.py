@@ -212,6 +212,25 @@ def test_bench_two_ranks_gloo_rehearsal_verifies_gathered_frame(gpus, steps, fix
     assert res["n_gpus"] == gpus and res["verified"] is True and res["value"] > 0 and res["scaling"] == "strong"
 
 
+@pytest.mark.parametrize("fail", ["1:1", "0:0"])
+def test_bench_rank_failure_ends_the_run_nonzero_and_fast(fail):
+    """`python bench.py --gpus 2` (gloo staging, both ranks on cuda:0) with one rank raising in the middle of the timed region (PT_BENCH_FAIL =
+    "rank:launch"): the failing rank reports and exits through bench.abort_rank, torch.distributed.run stops the other one, bench.py returns
+    non-zero with no result line -- in seconds, not at the collective timeout and never at the driver's limit."""
+    import os, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "PT_BENCH_BATCH", "PT_BENCH_SCHEDULE")}
+    env.update(PT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", PT_BENCH_FAIL=fail, PT_BENCH_TIMEOUT="60")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--width", "320", "--height", "180"],
+                       env=env, cwd=root, text=True, capture_output=True, timeout=300)
+    dt = time.time() - t0
+    assert r.returncode != 0
+    assert "injected failure (PT_BENCH_FAIL) on rank %s" % fail.split(":")[0] in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]          # no result line from a run that lost a rank
+    assert dt < 150, dt
+
+
 def test_bench_single_gpu_contract_line():
     """bench.py at N = 1 (small frame, few steps): ONE JSON line with the contract's keys, the roofline and CPU-baseline
     objects, a frame verified against the oracle, kernel busy time consistent with the step time, and the figures for the
@@ -233,7 +252,7 @@ def test_bench_single_gpu_contract_line():
     assert rf["frames_per_launch"] == 12.0 and rf["launches"] == 1
     # the timed region is repeated; the line carries the median repetition and the spread
     assert r["reps"] == 9 and len(r["ms_per_step_all"]) == 9 and r["ms_per_step_min_max"][0] <= r["ms_per_step"] <= r["ms_per_step_min_max"][1]
-    assert sorted(r["ms_per_step_all"])[4] == r["ms_per_step"]
+    assert sorted(r["ms_per_step_all"])[4] == r["ms_per_step"] and sorted(r["ms_per_step_all"][:5])[2] == r["ms_per_step_first5"]
     # ... and is followed by a second or so of back-to-back launches that end on the verified frame, bit for bit
     assert r["sustained"]["last_frame_identical_to_verified"] is True and r["sustained"]["frames"] >= 256 and r["sustained"]["seconds"] >= 1.0
     assert set(rf["peak_source"]) == {"l1_gather_requests", "valu_issue", "l2_bandwidth", "hbm_fabric"}

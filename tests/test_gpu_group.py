@@ -221,3 +221,25 @@ def test_group_rccl_two_members_on_two_gpus(rt, scene):
         one.close()
     finally:
         g.close()
+
+
+def test_group_create_with_more_devices_than_exist_is_an_error_with_a_message(rt):
+    """VERDICT r5 "next" 3: the first multi-GPU run must fail fast and say why.  A group over more devices than the process sees returns
+    PT_ERR_INVALID_ARG with the ordinal, the member and the device count in the message -- for both transports, through ctypes and through Node."""
+    import json, os, shutil, subprocess
+    import torch
+    have = torch.cuda.device_count()
+    for transport in (rt.PT_GROUP_TRANSPORT_RCCL, rt.PT_GROUP_TRANSPORT_COPY):
+        with pytest.raises(rt.PtError) as e:
+            rt.Group(list(range(have + 1)), transport)
+        assert e.value.code == 1
+        assert "device ordinal %d out of range" % have in str(e.value) and "sees %d HIP device" % have in str(e.value)
+    with pytest.raises(rt.PtError) as e:
+        rt.Group([0, -1], rt.PT_GROUP_TRANSPORT_COPY)
+    assert "device ordinal -1 out of range" in str(e.value)
+    node = shutil.which("node")
+    if node:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([node, os.path.join(root, "raytracer-public_amd", "js", "main.js"), "--gpus", str(have + 1), "--frames", "1", "--width", "64", "--height", "64", "--tris", "100"],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "out of range" in r.stderr

@@ -53,7 +53,7 @@ def test_build_bvh_end_to_end(rt, orc, gpu_ctx, n, seed):
     assert np.array_equal(gpu_ctx.read_bvh4(), bvh4)
 
 
-@pytest.mark.parametrize("kind", ["identical", "coplanar", "two_clusters", "tiny", "signed_zero"])
+@pytest.mark.parametrize("kind", ["identical", "coplanar", "two_clusters", "tiny", "signed_zero", "mixed_zero"])
 def test_build_bvh_degenerate_inputs(rt, orc, gpu_ctx, kind):
     """Equal Morton codes (index tie-break), zero extent on an axis (1e-20 floor), f16-subnormal bounds, -0 coordinates."""
     rng = np.random.default_rng(3)
@@ -67,6 +67,15 @@ def test_build_bvh_degenerate_inputs(rt, orc, gpu_ctx, kind):
         tris = np.concatenate([a, b]).reshape(-1)
     elif kind == "tiny":
         tris = rng.uniform(-3e-6, 3e-6, (400, 3, 3)).astype(np.float32).reshape(-1)     # below the f16 normal range
+    elif kind == "mixed_zero":
+        # +0, -0 and +-1e-9 (all +-0 in f16) mixed inside triangles and between siblings: min / max of (-0, +0) decides whether incrementF16
+        # (BVHBuilder.wgsl:63-82) lands on 0 or on the smallest subnormal -- pinned as -0 < +0 (oracle/pt_oracle.cpp::min_oz)
+        tris = rng.uniform(-1, 1, (600, 3, 3)).astype(np.float32)
+        zeros = np.array([0.0, -0.0, 1e-9, -1e-9, 4e-9, -4e-9], np.float32)
+        for axis in range(3):
+            pick = rng.random((600, 3)) < 0.5
+            tris[:, :, axis][pick] = zeros[rng.integers(0, 6, int(pick.sum()))]
+        tris = tris.reshape(-1)
     else:
         tris = rng.uniform(-1, 1, (256, 3, 3)).astype(np.float32)
         tris[::3, :, 0] = np.float32(-0.0); tris[1::3, :, 1] = np.float32(0.0); tris = tris.reshape(-1)
