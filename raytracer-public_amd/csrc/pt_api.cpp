@@ -41,16 +41,16 @@ struct DevBuf {
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto,
-             slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto, fork = kAuto, bounded = kAuto;
+             slots = kAuto, cull = kAuto, stats_batch = kAuto, quad = kAuto, fork = kAuto, bounded = kAuto, timeline = kAuto;
     uint32_t* find(const char* name) {
         static const struct { const char* n; uint32_t PtTune::* m; } tab[] = {
             {"GRIDDIV", &PtTune::grid_div}, {"ROWS", &PtTune::rows}, {"CHUNK", &PtTune::chunk}, {"XCD", &PtTune::xcd}, {"SHADE", &PtTune::shade},
-            {"FILL", &PtTune::fill}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}, {"FORK", &PtTune::fork}, {"BOUNDED", &PtTune::bounded}};
+            {"FILL", &PtTune::fill}, {"SLOTS", &PtTune::slots}, {"CULL", &PtTune::cull}, {"STATSBATCH", &PtTune::stats_batch}, {"QUAD", &PtTune::quad}, {"FORK", &PtTune::fork}, {"BOUNDED", &PtTune::bounded}, {"TIMELINE", &PtTune::timeline}};
         for (const auto& t : tab) if (std::strcmp(name, t.n) == 0) return &(this->*(t.m));
         return nullptr;
     }
     void from_environment() {
-        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL", "STATSBATCH", "QUAD", "FORK", "BOUNDED"};
+        static const char* names[] = {"GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL", "STATSBATCH", "QUAD", "FORK", "BOUNDED", "TIMELINE"};
         for (const char* n : names) {
             const std::string key = std::string("PT_TUNE_") + n;
             const char* v = std::getenv(key.c_str());
@@ -497,7 +497,10 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
     A.trace_slots = nullptr;
     const uint32_t cull_key[8] = {rect.tx0, rect.ty0, rect.tx1, rect.ty1, A.width, A.height, ctx->pending_rank | (ctx->pending_count << 16), A.num_trace_tiles};
     if (cull) { if (int rc = stage_traced_tiles(ctx, sl, cull_key, traced)) return rc; }
-    if (stats) {
+    // knob TIMELINE = 1 (diagnostics): an ordinary launch -- its plan, its slot, its overlap with its neighbours all as in production -- runs the TIMELINE variant
+    // of the kernel and leaves the per-wavefront record of pt_debug_wave_times (the last such launch's: read it after a pt_synchronize)
+    const bool timeline = !stats && PtTune::pick(ctx->tune.timeline, 0u) != 0u;
+    if (stats || timeline) {
         const uint32_t stat_waves = P.grid * ptk::megakernel_block() / 64u;
         PT_HIP(ctx, ctx->d_wave_times.ensure(size_t(stat_waves) * ptk::kWaveTimeWords));
         A.wave_times = ctx->d_wave_times.ptr; ctx->wave_times_n = stat_waves;
@@ -523,6 +526,7 @@ int flush_pending_stats(PtContext* ctx, bool stats, bool sharded, uint32_t count
         PT_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 24 * sizeof(unsigned long long), sl.side));
         PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(ctx->wave_times_n) * ptk::kWaveTimeWords * 8u, sl.side));
     }
+    if (timeline) PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.ptr, 0, size_t(ctx->wave_times_n) * ptk::kWaveTimeWords * 8u, sl.side));
     {   // per-frame parameters and targets into the slot's device arrays; a frame whose target a later frame of this launch
         // overwrites is marked (its result would not survive one-launch-per-frame rendering either)
         std::vector<ptk::FrameParams>& F = ctx->pending_frames;

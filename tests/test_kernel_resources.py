@@ -17,6 +17,24 @@ CSRC = os.path.join(os.path.dirname(HERE), "raytracer-public_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
 
 
+FLAGS = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -enable-post-misched=false -fvisibility=hidden".split()
+
+
+@pytest.fixture(scope="module")
+def megakernel_asm(tmp_path_factory):
+    """The device assembly of pt_megakernel.hip with the library's flags (compile-only, ~15 s), once per module."""
+    asm = tmp_path_factory.mktemp("mk") / "mk.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", *FLAGS, "-I" + os.path.join(os.path.dirname(HERE), "include"),
+                    "-S", "--cuda-device-only", os.path.join(CSRC, "pt_megakernel.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=900)
+    return asm.read_text()
+
+
+def kernel_body(text, instr, bounded):
+    """One variant's whole function (a variant may hold blocks behind its first s_endpgm)."""
+    start = text.index("_ZN3ptk18trace_paths_kernelILi%dELb%dEEEvNS_10RenderArgsE:" % (instr, bounded))
+    return text[start:text.index(".Lfunc_end", start)]
+
+
 @pytest.mark.skipif(HIPCC is None, reason="hipcc is missing")
 def test_megakernel_registers_scratch_and_occupancy_are_pinned():
     out = subprocess.run(["make", "-s", "-C", CSRC, "resource-usage"], capture_output=True, text=True, timeout=600)
@@ -25,34 +43,100 @@ def test_megakernel_registers_scratch_and_occupancy_are_pinned():
     seen = {}
     for b in blocks[1:]:
         name = b.split()[0]
-        m = re.match(r"_ZN3ptk18trace_paths_kernelILb([01])ELb([01])E", name)
+        m = re.match(r"_ZN3ptk18trace_paths_kernelILi([012])ELb([01])E", name)
         if not m:
             continue
         f = {k: int(v) for k, v in re.findall(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", b)}
         seen[(int(m.group(1)), int(m.group(2)))] = f
-    assert set(seen) == {(0, 0), (0, 1), (1, 0), (1, 1)}, sorted(seen)            # <STATS, BOUNDED>: all four variants are compiled
+    assert set(seen) == {(i, b) for i in (0, 1, 2) for b in (0, 1)}, sorted(seen)     # <INSTR, BOUNDED>: production, COUNTERS, TIMELINE x both reciprocal forms
     for bounded in (0, 1):                                                        # the production variants (no counters)
         f = seen[(0, bounded)]
         assert f["VGPRs"] <= 80, f
         assert f["ScratchSize [bytes/lane]"] == 0, f
         assert f["VGPRs Spill"] == 0, f
         assert f["Occupancy [waves/SIMD]"] >= 6, f
-        assert f["SGPRs Spill"] <= 24, f                                           # 15-21 over round 5, all of them in the cold paths (deep-stack spill area, launch prologue)
+        assert f["SGPRs Spill"] <= 18, f                                           # 17: the kernel-argument pointer, the workgroup id, launch constants -- none of them moved inside the traversal steps (next test)
         assert f["LDS Size [bytes/block]"] <= 160 * 1024 // 24, f                  # six single-wave workgroups per SIMD fit the CU's LDS
+    for bounded in (0, 1):
+        # the TIMELINE variant (tools/wave_timeline.py): production registers, production occupancy, NO scratch -- its bookkeeping is wave-uniform (scalar
+        # registers, events written when they happen), so what it times is the production kernel.  (The COUNTERS variant spills ~250 registers: never time with it.)
+        f = seen[(2, bounded)]
+        assert f["VGPRs"] <= 80 and f["ScratchSize [bytes/lane]"] == 0 and f["VGPRs Spill"] == 0 and f["Occupancy [waves/SIMD]"] >= 6, f
+        assert f["SGPRs Spill"] <= 48, f
+        assert seen[(1, bounded)]["ScratchSize [bytes/lane]"] > 0                   # if this ever becomes 0 the two variants can be merged again
+
+
+def loop_census(body):
+    """Per depth-2 loop of a kernel body: what it is and how many SGPR-spill moves (v_readlane / v_writelane) it executes outside the blocks that touch the
+    deep-stack spill area.  The logic of tools/isa_stats.sh: loop headers carry their depth and parents in the compiler's comments; every basic block names the
+    loop it is in; the TRAVERSAL STEPS are the depth-2 loop that pushes to the LDS stack (ds_write_b64) and does not claim queue items (global_atomic_add);
+    a block with a 64-bit global store without a scalar base or a 64-bit flat load is the deep-stack spill path (0.15 % of the pushes): cold."""
+    lines = body.split("\n")
+    depth_of, mid_of = {}, {}
+    for i, l in enumerate(lines):
+        m = re.match(r"^\.LBB(\d+_\d+)", l)
+        if not m:
+            continue
+        ctx = " ".join(lines[i:i + 6])
+        d = re.search(r"Loop Header: Depth=(\d+)", ctx)
+        if d:
+            label = m.group(1); depth_of[label] = int(d.group(1))
+            p2 = re.search(r"Parent Loop BB(\d+_\d+) Depth=2", ctx)
+            mid_of[label] = label if depth_of[label] == 2 else (p2.group(1) if p2 else None)
+    loops = {}
+    cur, blk = None, None
+    blocks = {}
+    for i, l in enumerate(lines):
+        m = re.match(r"^\.LBB(\d+_\d+)", l)
+        if m or re.match(r"^; %bb\.", l):
+            blk = i
+            if m and m.group(1) in depth_of:
+                cur = mid_of[m.group(1)] if depth_of[m.group(1)] >= 2 else None
+            else:
+                h = re.search(r"in Loop: Header=BB(\d+_\d+) Depth=(\d+)", l)
+                cur = mid_of.get(h.group(1)) if h and int(h.group(2)) >= 2 else None
+            blocks[blk] = {"loop": cur, "moves": 0, "cold": False}
+        t = l.strip()
+        if blk is None or not re.match(r"^(v_|s_|ds_|global_|scratch_|buffer_|flat_)", t):
+            continue
+        op = t.split()[0]
+        b = blocks[blk]
+        if op in ("v_readlane_b32", "v_writelane_b32"):
+            b["moves"] += 1
+        if (op == "global_store_dwordx2" and t.rstrip().endswith("off")) or op == "flat_load_dwordx2":
+            b["cold"] = True
+        if b["loop"] is not None:
+            k = loops.setdefault(b["loop"], {"push": False, "claim": False, "valu": 0, "all": 0})
+            k["all"] += 1
+            k["valu"] += op.startswith("v_")
+            k["push"] |= op in ("ds_write_b64", "ds_write2_b32")
+            k["claim"] |= op == "global_atomic_add"
+    for b in blocks.values():
+        if b["loop"] is not None:
+            loops[b["loop"]]["hot_moves"] = loops[b["loop"]].get("hot_moves", 0) + (0 if b["cold"] else b["moves"])
+    return loops
 
 
 @pytest.mark.skipif(HIPCC is None, reason="hipcc is missing")
-def test_the_step_waits_for_the_pieces_of_its_record_one_by_one(tmp_path):
+def test_no_sgpr_spill_move_inside_the_traversal_steps(megakernel_asm):
+    """The property that matters about the 17 spilled SGPRs: NONE of them is read or written inside the traversal steps of the production variants -- the loop
+    that runs 3.5 M times per frame and wavefront-step.  (The moves it contains sit in the blocks of the deep-stack spill path.)"""
+    for bounded in (0, 1):
+        loops = loop_census(kernel_body(megakernel_asm, 0, bounded))
+        steps = [k for k in loops.values() if k["push"] and not k["claim"]]
+        assert len(steps) == 3, (bounded, loops)                                 # the loop's three instances: dense, shadow rays to idle lanes, one ray per quad
+        for k in steps:
+            assert k["hot_moves"] == 0, (bounded, k)
+        dense = steps[0]
+        assert 440 <= dense["all"] <= 500 and dense["valu"] <= 265, dense         # 488 instructions, 262 of them vector, incl. the pop loop and the deep-stack blocks (tools/isa_stats.sh lists those apart: 441 / 239 + 37 / 15 + ...): a regression of the step shows here first
+
+
+@pytest.mark.skipif(HIPCC is None, reason="hipcc is missing")
+def test_the_step_waits_for_the_pieces_of_its_record_one_by_one(megakernel_asm):
     """Round 5: the traversal step asks for the four 16-byte pieces of its record at once and waits for them piece by piece (node side first: child 3, 2, 1, 0).
     That is a property of what the compiler emits -- load order and `s_waitcnt vmcnt(3..0)` placement --, not of the source alone: pinned here for the production
     variant's two one-ray-per-lane instances of the loop."""
-    flags = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -enable-post-misched=false -fvisibility=hidden".split()
-    asm = tmp_path / "mk.s"
-    subprocess.run([HIPCC, "--offload-arch=gfx950", *flags, "-I" + os.path.join(os.path.dirname(HERE), "include"),
-                    "-S", "--cuda-device-only", os.path.join(CSRC, "pt_megakernel.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=900)
-    text = asm.read_text()
-    start = text.index("_ZN3ptk18trace_paths_kernelILb0ELb1EEEvNS_10RenderArgsE:")
-    body = text[start:text.index("s_endpgm", start)]
+    body = kernel_body(megakernel_asm, 0, 1)
     lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
     groups = 0
     for i in range(len(lines) - 4):

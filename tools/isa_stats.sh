@@ -1,5 +1,6 @@
 #!/bin/bash
-# Static look at what the compiler made of trace_paths_kernel<false, true> (no counters, short reciprocal forms: the variant every ordinary launch runs): per loop depth of the three instances of the launch loop (one ray
+# Static look at what the compiler made of trace_paths_kernel<0, true> (no counters, short reciprocal forms: the variant every ordinary launch runs; INSTR=2 in the
+# environment looks at the TIMELINE variant instead, INSTR=1 at the COUNTERS one): per loop depth of the three instances of the launch loop (one ray
 # per lane / one ray per quad) the instruction count, vector instructions, register copies (v_mov_b32), idle issue slots (s_nop),
 # scratch accesses and SGPR-spill lane moves.  Round 4 found 2-3 % of a dense frame in things only this shows: ~220 register copies per
 # pass of the outer loop after an innocent-looking early exit, an `s_nop` behind every one-instruction asm statement, uniform flags spilled
@@ -9,7 +10,7 @@ cd "$(dirname "$0")/../raytracer-public_amd/csrc" || exit 1
 FL="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -enable-post-misched=false -fvisibility=hidden -I../../include $*"
 TMP=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $FL -S --cuda-device-only pt_megakernel.hip -o $TMP/mk.s 2>/dev/null || { echo "compile failed"; exit 1; }
-awk '/^_ZN3ptk18trace_paths_kernelILb0ELb1/,/s_endpgm/' $TMP/mk.s > $TMP/k.s
+awk "/^_ZN3ptk18trace_paths_kernelILi${INSTR:-0}ELb1/,/^\\.Lfunc_end/" $TMP/mk.s > $TMP/k.s      # the whole function: a variant may hold blocks behind its first s_endpgm
 python3 - $TMP/k.s <<'PY'
 import re, sys, collections
 lines = open(sys.argv[1]).read().split('\n')
@@ -67,5 +68,5 @@ for n, o in enumerate(big):
             what = ("loop BB%s, depth 2: %s" % (mid, kind)) if d == 2 else ("  its depth-%d loops (pop loop, deep-stack spill loop)" % d)
         print("  %s: %s" % (what, dict(c[o][(mid, d)])))
 PY
-make -s resource-usage EXTRA="$*" 2>&1 | grep -A9 "trace_paths_kernelILb0ELb1" | grep -E "VGPRs:|ScratchSize|Spill" | sed "s/.*remark: *//"
+make -s resource-usage EXTRA="$*" 2>&1 | grep -A9 "trace_paths_kernelILi${INSTR:-0}ELb1" | grep -E "VGPRs:|ScratchSize|Spill" | sed "s/.*remark: *//"
 rm -rf $TMP
