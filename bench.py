@@ -24,12 +24,14 @@ SURVEY 8d asks for at least 3) after the warm-up; `value` / `ms_per_step` are th
 every repetition in order.  (Nine since round 5: behind a 5-step warm-up the chip is still ramping -- twelve repetitions of the driver's command read 0.777, 0.727, 0.721,
 0.708, 0.717, 0.714, 0.705, 0.707, 0.705, 0.711, 0.703, 0.705 ms per step -- and the median of five sat on the ramp.)
 
-The JSON line's `roofline` carries the fractions of the four resources a gather-and-compute kernel can be bound by and names as `bound`
-the largest of them -- whatever it is; `bound_by_probe` next to it says which resource the kernel RESPONDS to (round 4's probe builds of the
-production step: it is the executed vector work, not the vector L1's request rate, whose fraction of a self-measured peak is the larger number;
-DESIGN.md section 7) -- each with the source of its peak (`peak_source`: "guide" = /opt/skills/guides/MI355X_MICROARCH.md, "probe" = measured by tools/probes/), with the
-kernel's busy time measured live (union of the per-launch hipEvent intervals on the launch streams, median repetition) and the
-per-frame counter totals taken from the rocprofv3 --pmc passes of THIS command committed under profiles/ (tools/pmc_bench.sh).  The
+The JSON line's `roofline`: `fractions` holds, for every resource a gather-and-compute kernel can be bound by (vector issue, scalar issue, L2 bandwidth, HBM-side
+traffic, the vector L1's request rate), per-frame counter total / kernel busy time / peak; `peaks` says where each peak comes from -- "guide" =
+/opt/skills/guides/MI355X_MICROARCH.md, "self-measured" = a probe under tools/probes/ -- and `bound` / `frac` are the largest fraction AMONG THE GUIDE PEAKS, so the
+headline can be recomputed from profiles/r06_pmc_bench.json and the guide alone.  The kernel's busy time is measured live (union of the per-launch hipEvent intervals on
+the launch streams, median repetition); the per-frame counter totals come from the rocprofv3 --pmc passes of THIS command committed under profiles/ (tools/pmc_bench.sh).
+`kernel` names the variant that actually ran (the host picks the reciprocal forms per scene and camera).  `lane_utilisation_by_side` decomposes the kernel's lane
+utilisation: wavefront-steps, traversing lanes and lanes at a leaf from one launch on the TIMELINE variant (production speed), against the static vector instructions
+of the step's sides.  `responds_to` carries what probe builds of the production step showed the kernel responds to.  The
 SURVEY 8d algorithmic byte rate is reported next to it, not as a fraction of a roof it does not touch: the scene is cache resident.
 `sustained` (N = 1): after the timed region the GPU renders for about 11 s in 32-frame launches -- the driver's 20 steps are 15 ms of GPU time,
 too short for any outside observer to see, and a utilisation sampler with a 5 s period needs two periods to be sure to land inside -- and the last of
@@ -66,7 +68,16 @@ L2_PEAK_GBS, L2_LINE, HBM_PEAK_GBS = 34500.0, 128, 8000.0
 # the vector L1's request rate for this access pattern (every lane gathers its own 64-byte record with 4 x dwordx4): 217.7 G records/s x 4
 # requests, measured chip-wide by tools/probes/gather64.hip (profiles/r03_gather64_probe.txt, V0) -- 1.42 requests per cycle and CU
 L1_GATHER_PEAK_GREQ = 217.7 * 4
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_bench.json")
+# the scalar unit: ONE per CU (guide glossary); its issue rate is not in the guide -- tools/probes/salu_rate.hip measures 586 G scalar instructions / s chip-wide with
+# 8 ... 32 resident wavefronts per CU (profiles/r06_salu_rate_probe.txt) = 0.953 of one instruction per CU and cycle at 2.4 GHz (the probe's own loop overhead is the rest);
+# a single wavefront issues one every ~4.5 cycles.  Peak used: 1 per CU and cycle.
+CUS = 256
+SALU_PEAK_GINST = CUS * CLOCK_HZ / 1e9
+# static vector instructions of one traversal step of the dense instance, by the lanes that execute them (compile-only census of this kernel build,
+# pinned by tests/test_kernel_resources.py::test_step_census_matches_bench_constants): node side = four slab tests + child order + the three stack stores,
+# leaf side = Moller-Trumbore, pop = the stack pop (its loop body again per skipped entry), common = fetch address + exit test
+STEP_VALU = {"node_side": 110, "leaf_side": 59, "pop": 14, "pop_per_entry": 5, "common": 6}
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_bench.json")
 KERNEL_SOURCES = ["pt_megakernel.hip", "pt_megakernel_loop.inc", "pt_device.h", "pt_kernels.h"]
 VERIFY_STEP = 4         # the timed frame is checked on every 4th pixel in x and y (1/16 of the frame, ~0.6 s of oracle time)
 SHARD_PIECES = 3        # launches a sharded run is cut into at least (tools/pieces_sweep.sh -> profiles/r05_m3_shard_pieces.txt: [7, 7, 6] beats [5, 5, 5, 5] by 2.5 .. 5.5 % at N = 2 / 4 / 8 once the last gather is added)
@@ -405,6 +416,7 @@ def run_bench(args, rank, world, device, backend, torch, dist, np, rt):
     import ctypes as C
     dbg = np.zeros(24, np.uint64)
     rays_entering = 0                # rays that enter the root box at all (camera rays that miss it are most of C2's "rays")
+    rcp_short_variant = True
     with torch.cuda.stream(stream):
         if sharded:
             ctx.set_compact_buffer(compact[0][0].data_ptr(), stride)
@@ -412,6 +424,7 @@ def run_bench(args, rank, world, device, backend, torch, dist, np, rt):
             ctx.render(params(i, stats=True))
             st = ctx.stats()
             rt.lib.pt_debug_counters(ctx.h, dbg.ctypes.data_as(C.c_void_p)); rays_entering += (int(dbg[7]) & ((1 << 63) - 1)) >> 1
+            rcp_short_variant = rcp_short_variant and bool(int(dbg[7]) & 1)      # which variant the host picks for this scene / camera (the same decision for the timed launches)
             frame_bytes.append(algorithmic_bytes(st))
             my_stats = st if my_stats is None else {k: my_stats[k] + st[k] for k in st}
     my_bytes = float(sum(frame_bytes)) / max(len(frame_bytes), 1)       # mean per frame
@@ -508,6 +521,45 @@ def run_bench(args, rank, world, device, backend, torch, dist, np, rt):
     elif not verified:
         ctx.close()
         sys.exit(3)
+
+    # ---- where the lanes are: one more launch of the timed shape on the TIMELINE variant of the kernel (production registers and speed; wave-uniform
+    #      counters in scalar registers): wavefront-steps, traversing lanes, lanes at a leaf -- the decomposition of the counter files' lane utilisation
+    lanes_by_side = None
+    if world == 1 and rank == 0:
+        import ctypes as C2
+        ctx.debug_set_tune("TIMELINE", 1)
+        with torch.cuda.stream(stream):
+            n_tl = min(batch, args.steps)
+            for j in range(n_tl):
+                p.frame = j
+                ctx.set_output_buffer(frames_out[j].data_ptr(), height * width * 4)
+                ctx.render(p)
+            if n_tl < batch:
+                ctx.flush()
+            ctx.synchronize()
+            tl_ms = ctx.last_render_ms()
+        ctx.debug_set_tune("TIMELINE")
+        wt = np.zeros((16384, 24), np.uint64); nw = C2.c_uint32()
+        rt.lib.pt_debug_wave_times(ctx.h, wt.ctypes.data_as(C2.c_void_p), C2.c_uint32(16384), C2.byref(nw))
+        wt = wt[: nw.value].astype(np.float64)
+        if len(wt) and wt[:, 3].sum() > 0 and int(wt[0, 20]) == 2:
+            steps_w, lanes, leaf = wt[:, 3].sum(), wt[:, 7].sum(), wt[:, 9].sum()
+            node = lanes - leaf
+            V = STEP_VALU
+            # the pop runs for the lanes that left a leaf or found no child (every leaf lane, plus the node lanes without a hit): bounded below by the leaf lanes
+            model = (V["node_side"] * node + V["leaf_side"] * leaf + V["pop"] * leaf + V["common"] * lanes) / (64.0 * steps_w * (V["node_side"] + V["leaf_side"] + V["pop"] + V["common"]))
+            lanes_by_side = {
+                "frames": n_tl, "wavefront_steps_per_frame": round(steps_w / n_tl, 1), "lane_steps_per_frame": round(lanes / n_tl, 1),
+                "lanes_per_step": {"traversing": round(lanes / steps_w, 2), "node_side": round(node / steps_w, 2), "leaf_side": round(leaf / steps_w, 2)},
+                "share_of_64_lanes": {"traversing": round(lanes / steps_w / 64.0, 4), "node_side": round(node / steps_w / 64.0, 4), "leaf_side": round(leaf / steps_w / 64.0, 4)},
+                "shade_passes_per_frame": round(wt[:, 4].sum() / n_tl, 1), "refill_passes_per_frame": round(wt[:, 5].sum() / n_tl, 1),
+                "static_valu_per_step": V,
+                "modelled_step_lane_utilisation": round(model, 4),
+                "launch_ms": round(tl_ms, 4),
+                "how": "one launch of the timed shape on trace_paths_kernel<2, *> (TIMELINE: the production kernel + wave-uniform counters in scalar registers, no scratch, "
+                       "same registers and occupancy; knob TIMELINE); node side = traversing lanes not at a leaf; model = sum(static vector instructions of a side x lanes "
+                       "executing it) / (64 x all of them): the step's share of the kernel-wide lane_utilisation, which also holds the shade and refill passes",
+            }
 
     # ---- the reference's own call shape: one render() per frame, no batching (src/main.js:70-74) ------------------------------
     ref_shape = None
@@ -640,17 +692,35 @@ def run_bench(args, rank, world, device, backend, torch, dist, np, rt):
         pmc_info["used"] = pmc_usable
         if pmc and not pmc_usable:
             pmc_info["why_unused"] = "source_tag differs (kernel edited since the passes: re-run tools/pmc_bench.sh)" if pmc_info.get("stale") else "the passes were taken over another command / launch shape"
+        # Every resource the kernel can be bound by: (counter expression per frame, peak, unit, where the peak comes from).  `bound` / `frac` are taken among the
+        # resources whose peak is a GUIDE figure (/opt/skills/guides/MI355X_MICROARCH.md); a peak this repository measured itself (tools/probes/) is reported,
+        # labelled, and never the headline.
+        GUIDE, PROBE = "guide", "self-measured"
+        resources = {
+            "valu_issue": ("valu", lambda c: c["SQ_INSTS_VALU"], VALU_PEAK_GINST, "Ginst/s", GUIDE, "SIMD-32: 2 cycles per wave64 instruction, 1,024 SIMDs, 2.4 GHz"),
+            "l2_bandwidth": ("l2", lambda c: (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE, L2_PEAK_GBS, "GB/s", GUIDE, "34.5 TB/s aggregate, 128-byte lines"),
+            "hbm_fabric": ("hbm", lambda c: (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, HBM_PEAK_GBS, "GB/s", GUIDE, "8 TB/s (FETCH_SIZE includes Infinity-Cache hits)"),
+            "salu_issue": ("salu", lambda c: c["SQ_INSTS_SALU"], SALU_PEAK_GINST, "Ginst/s", PROBE,
+                           "one scalar unit per CU (guide glossary) x one instruction per cycle (tools/probes/salu_rate.hip: 586 G/s of 614.4 measured, profiles/r06_salu_rate_probe.txt), 2.4 GHz"),
+            "l1_gather_requests": ("l1", lambda c: c["TCP_TOTAL_CACHE_ACCESSES_sum"], L1_GATHER_PEAK_GREQ, "Greq/s", PROBE,
+                                   "tools/probes/gather64.hip, profiles/r03_gather64_probe.txt: 871 G requests/s of a pure 64-byte-record gather"),
+        }
+        res_rates = {}
         if pmc_usable:
             c = pmc["per_frame"]
             s = busy_per_frame * 1e-3
 
             def fracs(sec):
-                extra = {"l1_gather_requests": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / sec / 1e9 / L1_GATHER_PEAK_GREQ} if "TCP_TOTAL_CACHE_ACCESSES_sum" in c else {}
-                return {**extra, "valu_issue": c["SQ_INSTS_VALU"] / sec / 1e9 / VALU_PEAK_GINST,
-                        "l2_bandwidth": (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE / sec / 1e9 / L2_PEAK_GBS,
-                        "hbm_fabric": (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / sec / 1e9 / HBM_PEAK_GBS}
+                out_f = {}
+                for name, (_, expr, peak, _, _, _) in resources.items():
+                    try:
+                        out_f[name] = expr(c) / sec / 1e9 / peak
+                    except KeyError:          # a counter the passes did not collect
+                        pass
+                return out_f
 
             fractions = fracs(s)
+            res_rates = {name: resources[name][1](c) / s / 1e9 for name in fractions}
             # the same counters over the kernel time of the session they were taken in (tools/pmc_bench.sh stores it): a 10 % difference
             # between that box and this one shows up as a difference between the two sets instead of hiding in `frac`
             bms = pmc.get("builder_kernel_busy_ms_per_frame")
@@ -659,40 +729,33 @@ def run_bench(args, rank, world, device, backend, torch, dist, np, rt):
                 pmc_info["builder_kernel_busy_ms_per_frame"] = bms
             lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
             traffic = int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 * frames_per_launch)
-            # `bound` = the largest fraction, whatever it is.  `bound_by_probe` (below) carries what probe builds of the production step showed the kernel
-            # responds to: 20 % fewer L1 requests per step bought nothing, every added vector / scalar instruction costs 0.1-0.25 %, and round 5's removal of
-            # ~12 vector instructions per step bought 4 % (profiles/r04_p1_step_sensitivity_probe.txt, r04_g1_fetch_pieces_ab.txt, r05_d1_dense_micro_ab.txt).
-            bound = max(fractions, key=fractions.get)
-            rooftab = {"l1_gather_requests": ("l1", c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / s / 1e9, L1_GATHER_PEAK_GREQ, "Greq/s"),
-                       "valu_issue": ("valu", c["SQ_INSTS_VALU"] / s / 1e9, VALU_PEAK_GINST, "Ginst/s"),
-                       "l2_bandwidth": ("l2", (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE / s / 1e9, L2_PEAK_GBS, "GB/s"),
-                       "hbm_fabric": ("hbm", (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / s / 1e9, HBM_PEAK_GBS, "GB/s")}
-            roof = rooftab[bound]
-            probe_roof = rooftab["valu_issue"]
+            guide_fracs = {k: v for k, v in fractions.items() if resources[k][4] == GUIDE}
+            bound = max(guide_fracs, key=guide_fracs.get)
+            roof = (resources[bound][0], res_rates[bound], resources[bound][2], resources[bound][3])
         else:
             roof = ("unmeasured", None, None, None)
-            probe_roof = None
+        variant = "trace_paths_kernel<0, %s>" % ("true" if rcp_short_variant else "false")
         roofline = {
             "bound": roof[0], "achieved": None if roof[1] is None else round(roof[1], 2), "peak": roof[2], "unit": roof[3],
             "frac": None if roof[1] is None else round(roof[1] / roof[2], 5), "traffic": traffic,
-            "bound_by_probe": None if probe_roof is None else {
-                "bound": probe_roof[0], "achieved": round(probe_roof[1], 2), "peak": probe_roof[2], "unit": probe_roof[3], "frac": round(probe_roof[1] / probe_roof[2], 5),
-                "evidence": "probe builds of the production step, same-session A/Bs: profiles/r04_p1_step_sensitivity_probe.txt (each added instruction costs 0.1-0.25 %), "
-                            "r04_g1_fetch_pieces_ab.txt (20 % fewer L1 requests: 2.5-3.6 % SLOWER), r05_d1_dense_micro_ab.txt (fewer vector instructions per step: faster by as much)"},
-            "kernel": "trace_paths_kernel<false, true> (persistent megakernel; no counters, short reciprocal forms)",
+            "bound_among": "resources whose peak is a guide figure (valu_issue, l2_bandwidth, hbm_fabric); self-measured peaks are listed in `fractions`, never the headline",
+            "kernel": "%s (persistent megakernel; INSTR 0 = no counters; BOUNDED %s = %s reciprocal / square-root forms, chosen by the host for this scene and these cameras: stats word 7 bit 0 of the instrumented launches)"
+                      % (variant, "true" if rcp_short_variant else "false", "short" if rcp_short_variant else "general"),
             "kernel_busy_ms": round(busy, 4), "kernel_busy_ms_per_frame": round(busy_per_frame, 5), "launches": int(len(k_ms)),
             "kernel_avg_launch_ms": round(float(np.mean(k_ms)), 4) if len(k_ms) else None, "frames_per_launch": frames_per_launch,
             "fractions": {k: round(v, 5) for k, v in fractions.items()},
-            "peak_source": {"l1_gather_requests": "probe (tools/probes/gather64.hip, profiles/r03_gather64_probe.txt: 871 G requests/s of a pure 64-byte gather)", "valu_issue": "guide (SIMD-32: 2 cycles per wave64 instruction, 1,024 SIMDs, 2.4 GHz)",
-                            "l2_bandwidth": "guide (34.5 TB/s)", "hbm_fabric": "guide (8 TB/s)"},
+            "rates": {k: round(v, 2) for k, v in res_rates.items()},
+            "peaks": {k: {"peak": resources[k][2], "unit": resources[k][3], "source": resources[k][4], "what": resources[k][5]} for k in resources},
             "fractions_over_builder_time": {k: round(v, 5) for k, v in fractions_builder.items()},
             "lane_utilisation": None if lane_util is None else round(lane_util, 4),
+            "lane_utilisation_by_side": lanes_by_side,
+            "responds_to": {"resource": "valu_issue", "evidence": "probe builds of the production step, same-session A/Bs: profiles/r04_p1_step_sensitivity_probe.txt (each added instruction costs 0.1-0.25 %), "
+                            "r04_g1_fetch_pieces_ab.txt (20 % fewer L1 requests: 2.5-3.6 % SLOWER), r05_d1_dense_micro_ab.txt (fewer vector instructions per step: faster by as much)"},
             "pmc": pmc_info,
             "definition": "frac = (per-frame counter total of the timed launches, rocprofv3 --pmc of this command, profiles/) / (kernel busy time per frame, hipEvents of this run) / peak; "
-                          "valu_issue: SQ_INSTS_VALU x 2 cycles over 1024 SIMDs x 2.4 GHz; l2_bandwidth: (TCC_HIT+TCC_MISS) x 128 B over 34.5 TB/s; "
-                          "hbm_fabric: (FETCH_SIZE+WRITE_SIZE) x 1024 over 8 TB/s (FETCH_SIZE includes Infinity-Cache hits); l1_gather_requests: TCP_TOTAL_CACHE_ACCESSES over the "
-                          "request rate a pure 64-byte-record gather sustains (871 G/s, tools/probes/gather64.hip); bound = the largest fraction; bound_by_probe = the resource probe builds showed the step responds to; fractions_over_builder_time = the same "
-                          "counters over the kernel time of the session the counters were taken in (another box: the two sets differ by the boxes' speed difference)",
+                          "valu_issue: SQ_INSTS_VALU x 2 cycles over 1024 SIMDs x 2.4 GHz; l2_bandwidth: (TCC_HIT+TCC_MISS) x 128 B over 34.5 TB/s; hbm_fabric: (FETCH_SIZE+WRITE_SIZE) x 1024 over 8 TB/s; "
+                          "salu_issue: SQ_INSTS_SALU over 256 CUs x 2.4 GHz; l1_gather_requests: TCP_TOTAL_CACHE_ACCESSES over 871 G/s; bound = the largest fraction among guide peaks; "
+                          "fractions_over_builder_time = the same counters over the kernel time of the session the counters were taken in (another box: the two sets differ by the boxes' speed difference)",
             "algorithmic": {"GBps": round(algorithmic_gbs, 2), "bytes_per_frame": int(my_bytes), "bytes_per_frame_min_max": [int(min(frame_bytes)), int(max(frame_bytes))],
                             "over_hbm_peak": round(algorithmic_gbs / HBM_PEAK_GBS, 4),
                             "note": "SURVEY 8d: 32 B x node records examined + 36 B x triangles tested + 16 B x samples, over the kernel busy time; the working set (67 MB) is "

@@ -255,7 +255,13 @@ def test_bench_single_gpu_contract_line():
     assert sorted(r["ms_per_step_all"])[4] == r["ms_per_step"] and sorted(r["ms_per_step_all"][:5])[2] == r["ms_per_step_first5"]
     # ... and is followed by a second or so of back-to-back launches that end on the verified frame, bit for bit
     assert r["sustained"]["last_frame_identical_to_verified"] is True and r["sustained"]["frames"] >= 256 and r["sustained"]["seconds"] >= 1.0
-    assert set(rf["peak_source"]) == {"l1_gather_requests", "valu_issue", "l2_bandwidth", "hbm_fabric"}
+    assert set(rf["peaks"]) == {"l1_gather_requests", "valu_issue", "salu_issue", "l2_bandwidth", "hbm_fabric"}
+    assert {k for k, v in rf["peaks"].items() if v["source"] == "guide"} == {"valu_issue", "l2_bandwidth", "hbm_fabric"}
+    assert rf["bound"] in ("valu", "l2", "hbm", "unmeasured")                         # the headline is taken among the guide peaks only
+    assert rf["kernel"].startswith("trace_paths_kernel<0, true>")                    # the variant that ran: this scene and camera are bounded
+    side = rf["lane_utilisation_by_side"]
+    assert side["frames"] == 12 and 0 < side["lanes_per_step"]["leaf_side"] < side["lanes_per_step"]["node_side"] < side["lanes_per_step"]["traversing"] <= 64
+    assert abs(side["lanes_per_step"]["node_side"] + side["lanes_per_step"]["leaf_side"] - side["lanes_per_step"]["traversing"]) < 0.02
     # the trace kernel is busy for most of the timed region and never longer than it
     assert 0.3 * r["ms_per_step"] * 12 < rf["kernel_busy_ms"] <= r["ms_per_step"] * 12 * 1.02
     assert rf["frac"] is None or 0.0 < rf["frac"] <= 1.0

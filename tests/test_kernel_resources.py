@@ -207,3 +207,33 @@ def test_no_asm_memory_load_without_an_output_operand():
                     assert "&" in dst, "%s:%d: a loaded vector register is not an early-clobber output (\"=&v\")" % (os.path.basename(path), line)
             assert re.search(r"s_waitcnt\s+(lgkmcnt|vmcnt)\(0\)", text), "%s:%d: the asm statement does not wait for its own load" % (os.path.basename(path), line)
     assert checked >= 1          # the hand-written pop loop (pt_megakernel_loop.inc) is such a statement
+
+
+@pytest.mark.skipif(HIPCC is None, reason="hipcc is missing")
+def test_step_census_matches_bench_constants(megakernel_asm):
+    """bench.py's `lane_utilisation_by_side` prices the lanes of a step's sides with static vector-instruction counts (bench.STEP_VALU).  Those are a property of
+    what the compiler emits for THIS source: re-derived here from the dense instance of the production variant -- the block with the twelve v_perm_b32 is the
+    node side's four slab tests, the block with the v_rcp_f32 the leaf side -- and compared (+- 8 instructions)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(os.path.dirname(HERE), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    body = kernel_body(megakernel_asm, 0, 1).split("\n")
+    blocks, cur = [], None
+    for l in body:
+        if re.match(r"^\.LBB", l) or re.match(r"^; %bb\.", l):
+            cur = {"valu": 0, "perm": 0, "rcp": 0, "stores": 0, "depth2": "Depth=2" in l}
+            blocks.append(cur)
+        t = l.strip()
+        if cur is None:
+            continue
+        cur["valu"] += t.startswith("v_")
+        cur["perm"] += t.startswith("v_perm_b32")
+        cur["rcp"] += t.startswith("v_rcp_f32")
+        cur["stores"] += t.startswith("ds_write_b64")
+    slab = next(i for i, b in enumerate(blocks) if b["perm"] == 12)                 # first instance = the dense one
+    order = blocks[slab + 1]                                                        # child order + stack words (executed when a child is hit)
+    stores = next(b for b in blocks[slab + 1: slab + 6] if b["stores"] == 3)        # the three unconditional LDS stores
+    leaf = next(b for b in blocks[slab:] if b["rcp"] == 1 and b["valu"] > 40)       # Moller-Trumbore
+    node_side = blocks[slab]["valu"] + order["valu"] + stores["valu"]
+    assert abs(node_side - bench.STEP_VALU["node_side"]) <= 8, (node_side, bench.STEP_VALU)
+    assert abs(leaf["valu"] + 3 - bench.STEP_VALU["leaf_side"]) <= 8, (leaf["valu"], bench.STEP_VALU)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The counter side of bench.py's roofline: rocprofv3 --pmc passes (one counter group per run, never combined with tracing) and one
 # --kernel-trace --stats run over THE COMMAND THE DRIVER RUNS (`python3 bench.py --steps 20 --warmup 5`), reduced to per-frame totals of
-# the timed trace_paths_kernel launches -> profiles/r05_pmc_bench.json (+ kernel stats CSV; the caller copies them there).  bench.py writes the order of its launches
+# the timed trace_paths_kernel launches -> profiles/r06_pmc_bench.json (+ kernel stats CSV; the caller copies them there).  bench.py writes the order of its launches
 # (warm-up / timed / reference call shape) to a side file, so the timed dispatches are picked by position, not guessed.
 # usage (on the GPU box): tools/pmc_bench.sh <outdir-under-gpurun_out> [bench.py arguments, default: --steps 20 --warmup 5]
 set -u

@@ -4,7 +4,7 @@ import collections, csv, glob, hashlib, json, os, sys
 
 out_dir, command = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "trace_paths_kernel<false"         # <false, true> / <false, false>: no counters, short / general reciprocal forms
+KERNEL = "trace_paths_kernel<0,"            # <0, true> / <0, false>: INSTR 0 = no counters; short / general reciprocal forms
 
 
 def _normalised_source(path):
