@@ -80,7 +80,7 @@ STEP_VALU = {"node_side": 110, "leaf_side": 59, "pop": 14, "pop_per_entry": 5, "
 PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_bench.json")
 KERNEL_SOURCES = ["pt_megakernel.hip", "pt_megakernel_loop.inc", "pt_device.h", "pt_kernels.h"]
 VERIFY_STEP = 4         # the timed frame is checked on every 4th pixel in x and y (1/16 of the frame, ~0.6 s of oracle time)
-SHARD_PIECES = 3        # launches a sharded run is cut into at least (tools/pieces_sweep.sh -> profiles/r05_m3_shard_pieces.txt: [7, 7, 6] beats [5, 5, 5, 5] by 2.5 .. 5.5 % at N = 2 / 4 / 8 once the last gather is added)
+SHARD_PIECES = 3        # launches a sharded run is cut into at least (tools/ab/pieces_sweep.sh -> profiles/r05_m3_shard_pieces.txt: [7, 7, 6] beats [5, 5, 5, 5] by 2.5 .. 5.5 % at N = 2 / 4 / 8 once the last gather is added)
 
 
 def _normalised_source(path):
@@ -165,7 +165,7 @@ def schedule(n_steps, batch, world, fixed_batch):
     Sharded (world > 1): the gather of launch b travels while launch b+1 traces, and the LAST launch's gather and its drain are
     exposed, so a run is cut into SHARD_PIECES launches of about equal size at least, never more than `batch` frames each, the last
     ones no larger than the ones before -- chosen from the one-GPU replay of every rank's submission sequence
-    (tools/shard_schedule_sim.py, tools/pieces_sweep.sh -> profiles/r05_m3_shard_pieces.txt).  PT_BENCH_SCHEDULE="10,10" overrides (replays only)."""
+    (tools/shard_schedule_sim.py, tools/ab/pieces_sweep.sh -> profiles/r05_m3_shard_pieces.txt).  PT_BENCH_SCHEDULE="10,10" overrides (replays only)."""
     forced = os.environ.get("PT_BENCH_SCHEDULE")
     if forced and world > 1 and not fixed_batch:
         sizes = [int(x) for x in forced.split(",") if x.strip()]

@@ -330,7 +330,7 @@ PT_API int  pt_group_read_rgba8(PtGroup* group, uint8_t* dst, uint64_t dst_bytes
 PT_API int  pt_group_read_tonemapped(PtGroup* group, int from_rgba8, uint8_t* dst, uint64_t dst_bytes);
 
 /* ---- diagnostics: NOT part of the drop-in surface -------------------------------------------------------------------------
- * Exported for this repository's own tests and tools (tests/test_gpu_parity.py, tools/sweep.sh, tools/wave_timeline.py); a binding
+ * Exported for this repository's own tests and tools (tests/test_gpu_parity.py, tools/ab/sweep.sh, tools/wave_timeline.py); a binding
  * for the reference has no use for them and they may change between builds of the library. */
 /* Override one launch heuristic of this context ("GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL",
  * "STATSBATCH", "QUAD", "FORK", "BOUNDED"); value 0xFFFFFFFF restores the measured default.  Launches the open batch first.  The same knobs are read

@@ -37,7 +37,7 @@ struct DevBuf {
 
 // Development overrides of the megakernel's launch heuristics.  kAuto = use the measured default for the launch at hand.
 // Read from PT_TUNE_* ONCE, when the context is created (a shipped library does not consult the environment per launch);
-// tests and tools/sweep.sh change them through pt_debug_set_tune.
+// tests and tools/ab/sweep.sh change them through pt_debug_set_tune.
 struct PtTune {
     static constexpr uint32_t kAuto = 0xFFFFFFFFu;
     uint32_t grid_div = kAuto, rows = kAuto, chunk = kAuto, xcd = kAuto, shade = kAuto, fill = kAuto,
@@ -308,7 +308,7 @@ struct PlanInput {
     uint32_t traced_batches;     // (frame, traced tile, sample) batches of 64 pixel-samples in the launch
     uint32_t batch_size;         // pt_set_batch of the context: what a FULL launch of the current setting carries
 };
-// ... and what they decide (measured defaults, each overridable through PtTune; sources: DESIGN.md section 6.1, profiles/HISTORY.md, tools/sweep.sh)
+// ... and what they decide (measured defaults, each overridable through PtTune; sources: DESIGN.md section 6.1, profiles/HISTORY.md, tools/ab/sweep.sh)
 struct LaunchPlan {
     uint32_t grid;               // workgroups of the persistent kernel
     uint32_t perm_rows, perm_cols, total_items, chunk_items, xcd_span;       // the queue's walk through the batches
@@ -320,7 +320,7 @@ struct LaunchPlan {
 int slots_for(const PtTune& tune, uint32_t frames, uint32_t tile_count, bool sharded) {
     // How many launches to keep in flight depends on the work in one launch (in whole frames): a long launch only needs its tail covered by the
     // next one (and each extra overlapped launch stretches every launch's own duration), small sharded launches need several in flight to fill
-    // the chip.  Measured: tools/sweep.sh SLOTS, tools/pipe_sweep.sh.
+    // the chip.  Measured: tools/ab/sweep.sh SLOTS, tools/ab/pipe_sweep.sh.
     const uint32_t w8 = frames * 8u / (tile_count ? tile_count : 1u);      // eighths of a whole frame
     const int n = int(PtTune::pick(tune.slots, w8 >= 256u ? 3u : (w8 >= 64u ? 4u : (w8 >= 16u ? PT_FRAME_SLOTS : (w8 >= 8u ? (sharded ? 4u : 6u) : (sharded ? 8u : PT_FRAME_SLOTS))))));
     return n < 1 ? 1 : (n > PtContext::kMaxSlots ? PtContext::kMaxSlots : n);
@@ -334,7 +334,7 @@ LaunchPlan plan_launch(const PtTune& tune, const PlanInput& in) {
     {   // A tile-sharded frame is a fraction of the work: fewer, denser wavefronts (measured: 1/8 frame best at grid/4); a batch of nf such frames is
         // nf times the work again.  A single whole frame: the grid shrinks with the launches already in flight (one render() per frame without host
         // waits, the reference's call shape: six frame slots, a quarter of the grid each -- 1.21 -> 1.01 ms per frame; a lone frame keeps the whole
-        // grid: 2.9 ms, 3.8 ms on a quarter of it).  tools/pipe_sweep.sh
+        // grid: 2.9 ms, 3.8 ms on a quarter of it).  tools/ab/pipe_sweep.sh
         uint32_t div = PtTune::pick(tune.grid_div, count >= 8u ? 4u : (count >= 2u ? 2u : std::min(4u, 1u + in.launches_in_flight)));
         if (nf > 1u) div = div > nf ? div / nf : 1u;
         if (div > 1u) P.grid = (P.grid + div - 1u) / div;
@@ -343,7 +343,7 @@ LaunchPlan plan_launch(const PtTune& tune, const PlanInput& in) {
     // Rows of the batch transposition (the order in which the queue walks the (frame, tile, sample) batches).  Rows that are a multiple or a divisor
     // of the frame count keep the frames of a launch aligned: all rows are at the same image position at the same time, so the frames share the BVH
     // nodes they pull through L2.  Long launches take one row per frame (few places in flight = locality); short launches cut every frame into 128
-    // segments (fine interleave of object and background tiles = balance when each wavefront only sees a few chunks).  tools/sweep.sh ROWS
+    // segments (fine interleave of object and background tiles = balance when each wavefront only sees a few chunks).  tools/ab/sweep.sh ROWS
     const uint32_t work8 = nf * 8u / count;
     // (one row per frame from 3 frames of work on: launches of 3 .. 7 frames of work 1 .. 7 % faster than with 128 segments per frame, profiles/r05_m2_midsize_rows.txt)
     P.perm_rows = PtTune::pick(tune.rows, work8 >= 24u ? nf : (work8 >= 8u ? 128u * nf : 64u * nf));
@@ -361,7 +361,7 @@ LaunchPlan plan_launch(const PtTune& tune, const PlanInput& in) {
     if (uint64_t(P.total_items) + uint64_t(grid_lanes / 64u + 1u) * P.chunk_items > 0xFFFFFFFFull) {
         P.error = "pt_render: launch too large for the 32-bit work-queue cursor (more than 2^32 - grid * chunk items; lower spp, the resolution or the batch)"; return P;
     }
-    {   // XCD-aware queue for long launches: 8 ranges of the logical item order, one cursor per XCD (chunk aligned; 0 = one queue).  Measured (tools/sweep.sh
+    {   // XCD-aware queue for long launches: 8 ranges of the logical item order, one cursor per XCD (chunk aligned; 0 = one queue).  Measured (tools/ab/sweep.sh
         // XCD): 32-frame launches +2..3.5 %, HBM fetch traffic halved (L2 hit rate 85 -> 91 %); no gain at 8 frames of work, a loss for a single frame
         const uint32_t per = (P.total_items + 7u) / 8u;
         P.xcd_span = PtTune::pick(tune.xcd, work8 >= 64u ? 1u : 0u) ? ((per + P.chunk_items - 1u) / P.chunk_items) * P.chunk_items : 0u;

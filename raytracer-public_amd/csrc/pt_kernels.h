@@ -21,7 +21,7 @@
 #define PT_MEGA_BLOCK 64           // threads per workgroup of the persistent kernel: single-wave groups free their CU slot as soon as the wave drains
 #endif
 #ifndef PT_SHADE_THRESHOLD
-#define PT_SHADE_THRESHOLD 16       // lanes waiting for a shade pass before one runs (or nothing traverses); 16 measured best in long launches, 8..16 equal for single frames (tools/sweep.sh SHADE)
+#define PT_SHADE_THRESHOLD 16       // lanes waiting for a shade pass before one runs (or nothing traverses); 16 measured best in long launches, 8..16 equal for single frames (tools/ab/sweep.sh SHADE)
 #endif
 #ifndef PT_QUAD
 #define PT_QUAD 1                  // 1: a wavefront with nothing left to start and at most PT_QUAD_LIVE paths goes on with one ray per quad of lanes (pt_megakernel.hip); 0: never; 2: quads from the first ray on (A/B builds)

@@ -526,7 +526,7 @@ def test_forked_shadow_rays_bit_exact(rt, gpu_ctx, orc):
     assert same_bits(got, want)
     for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested", "samples"):
         assert st[k] == ost[k], k
-    # quads from the first ray on (every shadow ray of a continuing path can be handed over) is an A/B build, not a knob: covered by tools/kvariants.sh
+    # quads from the first ray on (every shadow ray of a continuing path can be handed over) is an A/B build, not a knob: covered by tools/ab/kvariants.sh
     gpu_ctx.debug_set_tune("FORK")
 
 

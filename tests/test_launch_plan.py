@@ -1,6 +1,6 @@
 """The megakernel's launch heuristics (pt_api.cpp::plan_launch) as a pure function, pinned for the launch shapes bench.py uses: a lone whole frame,
 the driver's 20-frame launch, the sustained leg's 32-frame launches, launches of five 1/8 shares (the N = 8 run of earlier rounds; seven now) and the N = 2 run's of 64 halves.
-No GPU: pt_debug_launch_plan needs no context.  (What the numbers were measured with: DESIGN.md section 6.1, profiles/HISTORY.md, tools/sweep.sh, tools/pipe_sweep.sh.)"""
+No GPU: pt_debug_launch_plan needs no context.  (What the numbers were measured with: DESIGN.md section 6.1, profiles/HISTORY.md, tools/ab/sweep.sh, tools/ab/pipe_sweep.sh.)"""
 import ctypes as C
 import importlib
 

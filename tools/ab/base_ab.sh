@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-session A/B of the working tree against the library under tools/ab/raytracer_base (tools/ab/README), alternating, N rounds:
 # 32-frame launches, 20-frame launches with a sync (the driver's command), a lone frame, one render() per frame, C4.
-#   usage (GPU box): tools/base_ab.sh <out file under gpurun_out> [rounds]
+#   usage (GPU box): tools/ab/base_ab.sh <out file under gpurun_out> [rounds]
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$1; N=${2:-2}; mkdir -p $(dirname $OUT); : > $OUT
 run() { "$@" 2>&1 | tail -1; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-session A/B of megakernel build variants (-D flags) on the launches that matter: 32-frame launches (throughput), 20-frame
 # launches with a sync (the driver's command), a lone frame, one render() per frame without waits, a 1/8 tile share in 20-frame
-# launches, and C4.   usage (GPU box): tools/kvariants.sh <out file under gpurun_out> "<flags of variant 1>" "<flags of variant 2>" ...
+# launches, and C4.   usage (GPU box): tools/ab/kvariants.sh <out file under gpurun_out> "<flags of variant 1>" "<flags of variant 2>" ...
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$1; shift; mkdir -p $(dirname $OUT); : > $OUT
 run() { "$@" 2>&1 | tail -1; }

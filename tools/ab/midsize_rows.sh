@@ -1,6 +1,6 @@
 #!/bin/bash
 # Where does "one row per frame" start to beat "128 segments per frame"?  Whole frames and half shares, 3 .. 8 frames of work per launch, isolated launches.
-#   usage (GPU box): tools/midsize_rows.sh <out file under gpurun_out>
+#   usage (GPU box): tools/ab/midsize_rows.sh <out file under gpurun_out>
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$1; mkdir -p $(dirname $OUT); : > $OUT
 run() { "$@" 2>&1 | tail -1; }

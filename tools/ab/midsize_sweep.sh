@@ -1,7 +1,7 @@
 #!/bin/bash
 # Launch heuristics (rows of the batch transposition, XCD-aware queue) for MID-SIZE launches: 2.5 .. 10 frames of work per launch -- what the sharded runs of bench.py
 # and 8-frame batches submit.  One session; every line = tools/pipeline_bench.py with the knobs in its label.
-#   usage (GPU box): tools/midsize_sweep.sh <out file under gpurun_out>
+#   usage (GPU box): tools/ab/midsize_sweep.sh <out file under gpurun_out>
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$1; mkdir -p $(dirname $OUT); : > $OUT
 run() { "$@" 2>&1 | tail -1; }

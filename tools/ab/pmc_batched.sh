@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of a batched (32-frame) trace_paths_kernel launch: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes
-# (never combined with tracing).  usage: tools/pmc_batched.sh <outdir-under-gpurun_out>
+# (never combined with tracing).  usage: tools/ab/pmc_batched.sh <outdir-under-gpurun_out>
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Which unit limits trace_paths_kernel?  rocprofv3 --pmc passes (one counter group per run, never combined with tracing) over
-# a 32-frame launch of tools/pipeline_bench.py.  usage: tools/pmc_discover.sh <outdir-under-gpurun_out> [scene]
+# a 32-frame launch of tools/pipeline_bench.py.  usage: tools/ab/pmc_discover.sh <outdir-under-gpurun_out> [scene]
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $OUT

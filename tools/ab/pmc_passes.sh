@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 PMC passes over tools/profile_frame.py (each pass its own run; --pmc is never combined
-# with tracing).  usage: tools/pmc_passes.sh <outdir-under-gpurun_out>
+# with tracing).  usage: tools/ab/pmc_passes.sh <outdir-under-gpurun_out>
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $OUT

@@ -3,7 +3,7 @@
 #   PT_TUNE_QUAD=0   one ray per lane throughout
 #   defaults         paths re-seated one per quad once a wavefront has nothing left to start and <= 16 paths
 # (the run recorded in profiles/r04_q1_quad_vs_consolidation_ab.txt also had round 3's drain consolidation in the tree: PT_TUNE_CONSOLIDATE)
-# on the launches that matter.  usage (GPU box): tools/quad_ab.sh <out file under gpurun_out>
+# on the launches that matter.  usage (GPU box): tools/ab/quad_ab.sh <out file under gpurun_out>
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$1; mkdir -p $(dirname $OUT); : > $OUT
 run() { "$@" 2>&1 | tail -1; }

@@ -3,7 +3,7 @@
 # of a launch?  Same-session A/B of two builds -- the default (one ray per lane while there is work to start, quads for the drain) and
 # -DPT_QUAD=2 (quads from the first ray on) -- with timings and the counters the question is about: vector-L1 accesses
 # (TCP_TOTAL_CACHE_ACCESSES), vector / scalar instructions, lane utilisation, per frame of 32-frame C2 launches (rocprofv3 --pmc passes,
-# never combined with tracing).   usage (GPU box): tools/quad_dense_ab.sh <out dir under gpurun_out>
+# never combined with tracing).   usage (GPU box): tools/ab/quad_dense_ab.sh <out dir under gpurun_out>
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $OUT; : > $OUT/summary.txt
 export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-session A/B of the resolve pass's workgroup size (256 / 128 / 64 threads): does a smaller group find a wave slot sooner next to the persistent launches?
-#   usage (GPU box): bash tools/resolve_block_ab.sh
+#   usage (GPU box): bash tools/ab/resolve_block_ab.sh
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r04_v3_resolve_block.txt; : > $OUT
 for V in "" "-DPT_RESOLVE_BLOCK=64" "-DPT_RESOLVE_BLOCK=128" ""; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One-GPU replay of every rank's submission sequence for the driver's sharded commands (tools/shard_schedule_sim.py), for the
 # schedule bench.py uses and for candidate schedules, in ONE session (box-to-box variance is ~10 %).
-#   usage (GPU box): tools/shard_schedule_sweep.sh <out file under gpurun_out>
+#   usage (GPU box): tools/ab/shard_schedule_sweep.sh <out file under gpurun_out>
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$1; mkdir -p $(dirname $OUT); : > $OUT
 sim() { python3 tools/shard_schedule_sim.py "$@" 2>&1 | grep -v "^$" >> $OUT; }

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Same-session A/B of one launch heuristic (PT_TUNE_<KNOB>) on the launches that matter (the set of tools/kvariants.sh), current build.
-#   usage (GPU box): tools/tune_ab.sh <out file under gpurun_out> KNOB v1 v2 ...      e.g. tools/tune_ab.sh quad.txt QUAD 0 16 0 16
+# Same-session A/B of one launch heuristic (PT_TUNE_<KNOB>) on the launches that matter (the set of tools/ab/kvariants.sh), current build.
+#   usage (GPU box): tools/ab/tune_ab.sh <out file under gpurun_out> KNOB v1 v2 ...      e.g. tools/ab/tune_ab.sh quad.txt QUAD 0 16 0 16
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$1; KNOB=$2; shift 2; mkdir -p $(dirname $OUT); : > $OUT
 run() { "$@" 2>&1 | tail -1; }

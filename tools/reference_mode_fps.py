@@ -25,7 +25,7 @@ def run(name, mode, batch=1, simple=False, lone=False, n=480):
 
 
 run("PT_MODE_REFERENCE, megakernel, one render() per launch", rt.PT_MODE_REFERENCE)
-if os.environ.get("PT_TUNE_SLOTS"): sys.exit(0)      # tools/ref_sweep.sh only wants the first line
+if os.environ.get("PT_TUNE_SLOTS"): sys.exit(0)      # tools/ab/ref_sweep.sh only wants the first line
 run("PT_MODE_REFERENCE, megakernel, 8 frames per launch", rt.PT_MODE_REFERENCE, batch=8)
 run("PT_MODE_REFERENCE, megakernel, 32 frames per launch", rt.PT_MODE_REFERENCE, batch=32)
 run("PT_MODE_REFERENCE, megakernel, lone frames (host waits)", rt.PT_MODE_REFERENCE, lone=True, n=200)
