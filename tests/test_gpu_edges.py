@@ -462,3 +462,55 @@ def test_packed_shares_rebuild_every_frame(rt, gpu_ctx, w, h, world, cam, spp):
             gpu_ctx.unpack_batch(p_ptr.value, frames * pstride, pstride, frames, w, h, world, (0, 0, tiles_x + 1, tiles_y), spp)     # rectangle outside the image
     finally:
         hip.hipFree(c_ptr); hip.hipFree(p_ptr); hip.hipFree(f_ptr)
+
+
+def test_timeline_variant_same_bits_and_a_sane_record(rt, gpu_ctx, orc):
+    """The TIMELINE variant of the megakernel (knob TIMELINE; tools/wave_timeline.py, bench.py's lane_utilisation_by_side) is the production kernel plus
+    wave-uniform bookkeeping: the image is the production variant's (and the oracle's) bit for bit -- single launches, a batched launch, a tile share --,
+    and every wavefront leaves a record that adds up: begin <= queue-dry <= end, lanes at a leaf <= traversing lanes <= 64 x steps, the snapshot taken when
+    the queue ran dry <= the totals.  With the knob off again no record is written."""
+    import ctypes as C
+    import orc as orc_mod
+    tris = rt.procedural_scene(0, 60000)
+    gpu_ctx.set_triangles(tris); gpu_ctx.build_bvh()
+    bvh4 = gpu_ctx.read_bvh4()
+    w, h = 640, 360
+    kw = dict(mode=rt.PT_MODE_PATH, spp=4, max_bounces=8, seed=2)
+    gpu_ctx.render(gpu_ctx.make_params(w, h, frame=3, **kw))
+    want = gpu_ctx.read_radiance().copy()
+    ref, _, ost = orc.render(orc.make_params(w, h, tris.size // 9, mode=orc_mod.MODE_PATH, spp=4, max_bounces=8, seed=2, frame=3), tris, bvh4)
+    assert np.array_equal(want.view(np.uint32), ref.view(np.uint32))
+
+    def record():
+        buf = np.zeros((8192, 24), np.uint64); n = C.c_uint32()
+        rt.lib.pt_debug_wave_times(gpu_ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_uint32(8192), C.byref(n))
+        return buf[: n.value].astype(np.int64)
+
+    gpu_ctx.debug_set_tune("TIMELINE", 1)
+    gpu_ctx.render(gpu_ctx.make_params(w, h, frame=3, **kw))
+    assert np.array_equal(gpu_ctx.read_radiance().view(np.uint32), want.view(np.uint32))
+    r = record()
+    assert len(r) >= 1024 and (r[:, 20] == 2).all()                              # every wavefront of the grid wrote its record, as the TIMELINE variant
+    ran = r[:, 3] > 0
+    assert ran.any()
+    assert (r[:, 0] <= r[:, 2]).all() and (r[ran, 0] <= r[ran, 1]).all() and (r[ran, 1] <= r[ran, 2]).all()        # begin <= queue dry <= end
+    assert (r[:, 9] <= r[:, 7]).all() and (r[:, 7] <= 64 * r[:, 3]).all()                                           # leaf lanes <= traversing lanes <= 64 x steps
+    assert (r[:, 6] <= r[:, 3]).all() and (r[:, 8] <= r[:, 7]).all() and (r[:, 15] <= r[:, 4]).all()                # the queue-dry snapshot <= the totals
+    assert (r[:, 10:14] == 0).all()                                                                                # cycle shares: COUNTERS variant only
+    steps_c, lanes_c = r[:, 3].sum(), r[:, 7].sum()
+    # the counts are the algorithm's, not the variant's: the COUNTERS variant of the same frame steps the same lanes (wavefront-steps vary with scheduling, lane-steps do not)
+    gpu_ctx.debug_set_tune("TIMELINE")
+    gpu_ctx.render(gpu_ctx.make_params(w, h, frame=3, stats=True, **kw))
+    st = gpu_ctx.stats()
+    rc = record()
+    assert (rc[:, 20] == 1).all() and rc[:, 7].sum() == lanes_c and abs(int(rc[:, 3].sum()) - int(steps_c)) < 0.05 * steps_c
+    for k in ("rays_closest", "rays_shadow", "nodes_examined", "tris_tested"):
+        assert st[k] == ost[k]
+    # a batched launch and a tile share on the TIMELINE variant: the same bits
+    gpu_ctx.debug_set_tune("TIMELINE", 1)
+    gpu_ctx.set_batch(3)
+    for f in (1, 2, 3):
+        gpu_ctx.render(gpu_ctx.make_params(w, h, frame=f, **kw))
+    assert np.array_equal(gpu_ctx.read_radiance().view(np.uint32), want.view(np.uint32))
+    gpu_ctx.set_batch(1)
+    gpu_ctx.debug_set_tune("TIMELINE")
