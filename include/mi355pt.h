@@ -333,8 +333,9 @@ PT_API int  pt_group_read_tonemapped(PtGroup* group, int from_rgba8, uint8_t* ds
  * Exported for this repository's own tests and tools (tests/test_gpu_parity.py, tools/ab/sweep.sh, tools/wave_timeline.py); a binding
  * for the reference has no use for them and they may change between builds of the library. */
 /* Override one launch heuristic of this context ("GRIDDIV", "ROWS", "CHUNK", "XCD", "SHADE", "FILL", "SLOTS", "CULL",
- * "STATSBATCH", "QUAD", "FORK", "BOUNDED"); value 0xFFFFFFFF restores the measured default.  Launches the open batch first.  The same knobs are read
- * from PT_TUNE_<NAME> once, when a context is created. */
+ * "STATSBATCH", "QUAD", "FORK", "BOUNDED", "TIMELINE"); value 0xFFFFFFFF restores the measured default.  Launches the open batch first.  The same knobs are read
+ * from PT_TUNE_<NAME> once, when a context is created.  "TIMELINE" = 1: ordinary (non-STATS) megakernel launches run the TIMELINE variant of the kernel --
+ * the production kernel plus wave-uniform bookkeeping in scalar registers, same registers / occupancy, no scratch -- and leave the record pt_debug_wave_times reads. */
 PT_API int pt_debug_set_tune(PtContext* ctx, const char* name, uint32_t value);
 /* The launch heuristics as a pure function of the launch's shape (no GPU, no context; the measured defaults): out[12] = workgroups, rows / columns of
  * the queue's batch transposition, logical items, items per claim, items per XCD range (0: one queue), shade / fill thresholds, paths at which a
@@ -343,8 +344,11 @@ PT_API int pt_debug_launch_plan(uint32_t num_cus, uint32_t frames, uint32_t tile
 /* Raw counter block (24 words) of the last PT_FLAG_STATS launch: PtStats order in [0..6], then the instrumented megakernel's own
  * diagnostics (stack pushes by depth, longest path / ray in traversal steps, re-seated wavefronts, ...). */
 PT_API int pt_debug_counters(PtContext* ctx, unsigned long long* dst24);
-/* Per-wavefront timeline of the last PT_FLAG_STATS megakernel launch: 24 words per wavefront (begin / queue-dry / end ticks, loop
- * counts, cycle shares); *n_waves = wavefronts written (<= max_waves). */
+/* Per-wavefront timeline of the last PT_FLAG_STATS or TIMELINE megakernel launch, 24 words per wavefront: [0] begin, [1] queue found dry, [2] end (100 MHz ticks),
+ * [3] traversal steps, [4] shade passes, [5] refill passes, [6] steps / [8] traversing lanes / [15] shade passes when the queue ran dry, [7] traversing lanes summed
+ * over the steps, [9] of them at a leaf, [16..18] tick / steps / lanes when the wavefront re-seated its paths one per quad (0: never), [20] the variant that wrote it
+ * (1 COUNTERS, 2 TIMELINE); COUNTERS only: [10..13] cycle shares (shade, refill, step, step before queue-dry), [14] longest path that ended after queue-dry, [19].
+ * *n_waves = wavefronts written (<= max_waves).  Read it after pt_synchronize. */
 PT_API int pt_debug_wave_times(PtContext* ctx, unsigned long long* dst, uint32_t max_waves, uint32_t* n_waves);
 
 #ifdef __cplusplus
