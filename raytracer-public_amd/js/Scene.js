@@ -306,6 +306,29 @@ class Scene {
     console.log("Mesh normalized.");
   }
 
+  // Scene.js:169-224 (the reference keeps its call commented out, :41; the method is part of the class all the same).  Orders the triangles along
+  // a 30-bit Morton curve of their centroids inside the centroids' bounding box.  Same arithmetic as the reference, key by key: the normalised coordinate
+  // times 1024, clamped to [0, 1023] and NOT truncated before the bit spreading -- each `(v * k) & mask` step truncates its own product (ToInt32), so
+  // the fraction takes part in the first step.  The reference hands a comparator that recomputes both codes to Array.prototype.sort; the codes are
+  // computed once per triangle here and sorted with the same stable sort (V8's), which gives the same order.
+  sortTriangles() {
+    if (this.triangles.length === 0) return;
+    console.log("Sorting " + this.triangles.length + " triangles spatially...");
+    const lo = [Infinity, Infinity, Infinity], hi = [-Infinity, -Infinity, -Infinity];
+    for (const t of this.triangles)
+      for (let k = 0; k < 3; k++) { lo[k] = Math.min(lo[k], t.centroid[k]); hi[k] = Math.max(hi[k], t.centroid[k]); }
+    const extent = [hi[0] - lo[0] || 1, hi[1] - lo[1] || 1, hi[2] - lo[2] || 1];
+    const spread = function (v) {
+      v = (v * 0x00010001) & 0xff0000ff; v = (v * 0x00000101) & 0x0f00f00f; v = (v * 0x00000011) & 0xc30c30c3; v = (v * 0x00000005) & 0x49249249;
+      return v;
+    };
+    const axis = function (c, k) { return spread(Math.min(Math.max(((c - lo[k]) / extent[k]) * 1024, 0), 1023)); };
+    const keyed = this.triangles.map(function (t) { return { t: t, code: axis(t.centroid[0], 0) | (axis(t.centroid[1], 1) << 1) | (axis(t.centroid[2], 2) << 2) }; });
+    keyed.sort(function (a, b) { return a.code - b.code; });
+    for (let i = 0; i < keyed.length; i++) this.triangles[i] = keyed[i].t;
+    console.log("Sorting complete.");
+  }
+
   // Scene.js:230-241
   getTrianglesFloat32() {
     const arr = new Float32Array(this.triangles.length * 9);
