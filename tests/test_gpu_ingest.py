@@ -4,7 +4,8 @@
       and primitives, TRS + matrix nodes, u16 and u32 index buffers, interleaved views) -> `node js/main.mjs --glb ...` = Scene.loadGLB
       (normalize: true, mode "cube", src/main.js:20-23) -> setScene -> BVH2 dump -> render.  The triangles the loader produced equal the independent
       numpy glTF rules' (f32 rounding), data/BVH2.bin equals the oracle's LBVH2 of them word for word, and the frame equals the oracle's on every pixel.
-  C2  "Stanford Dragon (data/BVH2.bin)": the 871,414-triangle run's data/BVH2.bin, loaded by a FRESH process through setBVH2 (file -> collapse ->
+  C2  the same at the reference's own scene size: an 871,414-triangle GLB through loadGLB, from the reference's camera; and
+      "Stanford Dragon (data/BVH2.bin)": the 871,414-triangle run's data/BVH2.bin, loaded by a FRESH process through setBVH2 (file -> collapse ->
       render), gives the build path's frame bit for bit (and the oracle's on a pixel grid).
 
 Plus the failure behaviour of the drivers: a GLB that exists and cannot be read ends the process non-zero; only an absent one falls back."""
@@ -69,6 +70,39 @@ def test_c4_sponza_class_glb_through_loadglb_full_size(tmp_path, rt, orc):
     img = np.fromfile(str(tmp_path / "img.f32"), np.float32).reshape(h, w, 4)
     assert same_bits(img, ref)
     assert ost["rays_closest"] > 4 * ost["samples"]                   # an interior: long paths, nearly every camera ray hits
+
+
+def test_c2_dragon_class_glb_through_loadglb_full_size(tmp_path, rt, orc):
+    """src/main.js:18-46 as written, at the size of the reference's own scene: an 871,414-triangle GLB (the dragon-class mesh through tests/glb_writer.py:
+    14.6 MB, u16 and u32 index buffers, interleaved views, TRS / matrix / mirrored nodes) -> loadGLB(normalize: true, mode "cube") -> setScene -> BVH2
+    dump -> render from the reference's camera (0, 0, 2.5).  Triangles against the numpy glTF rules, data/BVH2.bin against the oracle's LBVH2 word for
+    word, the 1080p / 4 spp / 8-bounce frame against the oracle on every 4th pixel in x and y (all samples)."""
+    from glb_writer import write_realistic_glb, normalize_cube
+    n = 871414
+    soup = rt.procedural_scene(rt.SCENE_DRAGON_CLASS, n)
+    glb = str(tmp_path / "dragon_class.glb")
+    expect, stats = write_realistic_glb(glb, soup, seed=7)
+    assert stats["u32"] >= 1 and stats["u16"] >= 2
+    want_tris, _, _ = normalize_cube(expect)
+    w, h = 1920, 1080
+    rc, out, err = run_node([MAIN_MJS, "--glb", glb, "--mode", "2", "--spp", "4", "--bounces", "8", "--seed", "1", "--frames", "1", "--width", str(w), "--height", str(h),
+                             "--dump", str(tmp_path / "data" / "BVH2.bin"), "--radiance", str(tmp_path / "img.f32"), "--triangles", str(tmp_path / "tris.f32")], str(tmp_path))
+    assert rc == 0, err
+    m = re.search(r"Loaded .* -> (\d+) triangles in (\d+) ms", out)
+    assert m and int(m.group(1)) == n, out
+    print("Scene.loadGLB: %d triangles (%d-byte GLB) in %s ms" % (n, os.path.getsize(glb), m.group(2)))
+    tris = np.fromfile(str(tmp_path / "tris.f32"), np.float32)
+    assert tris.size == n * 9
+    assert np.allclose(tris.reshape(-1, 3, 3), want_tris.astype(np.float32), rtol=2e-6, atol=2e-6)
+    morton, tri_index = rt.morton_sort(tris)
+    bvh2 = np.fromfile(str(tmp_path / "data" / "BVH2.bin"), np.uint32)
+    assert bvh2.size == 1 + 6 * (2 * n - 1)
+    assert np.array_equal(bvh2, orc.build_lbvh2(tris, morton, tri_index))
+    bvh4, _ = orc.collapse_bvh4(bvh2, n)
+    ref, _, _ = orc.render(orc.make_params(w, h, n, mode=orc_mod.MODE_PATH, spp=4, max_bounces=8, seed=1, frame=1, step=(4, 4)), tris, bvh4)
+    img = np.fromfile(str(tmp_path / "img.f32"), np.float32).reshape(h, w, 4)
+    assert same_bits(img[::4, ::4], ref[::4, ::4])
+    assert (img[..., 0] > 0.011).mean() > 0.08                        # the mesh is in front of the reference's camera
 
 
 def test_c2_bvh2_bin_reloaded_by_a_fresh_process(tmp_path, rt, orc):
