@@ -12,6 +12,9 @@
 //   node raytracer-public_amd/js/main.js [--frames N] [--width W --height H] [--mode 0|1|2]
 //        [--spp S --bounces B --seed K] [--glb path] [--tris N] [--batch F] [--out frame.ppm] [--dump data/BVH2.bin] [--bvh2 data/BVH2.bin]
 //        [--gpus N [--transport copy] | --devices 0,0,0]     one image per render() from N GPUs (pixel tiles, RCCL gather)
+//        [--bvh4-wide [--dump-wide data/BVH4_wide.bin]]      traverse the BVH4_wide promotion of the BVH2 (tests/test.cpp: config C3) instead of the collapsed BVH4
+//        [--accumulate]                                      progressive accumulation over the frames (config C5; no warm-up frame then)
+//        [--cam x,y,z --quat x,y,z,w] [--radiance frame.f32 --triangles tris.f32]
 "use strict";
 const fs = require("fs");
 const path = require("path");
@@ -19,14 +22,16 @@ const PT = require("./PathTracer.js");
 const PTScene = require("./Scene.js");
 
 function arg(name, dflt) { const i = process.argv.indexOf("--" + name); return i >= 0 && i + 1 < process.argv.length ? process.argv[i + 1] : dflt; }
+function flag(name) { return process.argv.indexOf("--" + name) >= 0; }
 
 async function main() {
   const canvas = { width: Number(arg("width", 1920)), height: Number(arg("height", 1080)) };   // index.html:10
   const mode = Number(arg("mode", PT.MODE_REFERENCE));
   const devices = arg("devices", null);
-  const pathTracer = new PT.PathTracer(canvas, { mode: mode, spp: Number(arg("spp", 4)), maxBounces: Number(arg("bounces", 8)), seed: Number(arg("seed", 1)),
+  const accumulate = flag("accumulate");
+  const pathTracer = new PT.PathTracer(canvas, { mode: mode, spp: Number(arg("spp", 4)), maxBounces: Number(arg("bounces", 8)), seed: Number(arg("seed", 1)), accumulate: accumulate,
                                                  gpus: Number(arg("gpus", 1)), devices: devices ? devices.split(",").map(Number) : null, transport: arg("transport", "rccl") });
-  const camera = { position: [0, 0, 2.5], rotation: [0, 0, 0, 1] };                             // src/main.js:10-14
+  const camera = { position: arg("cam", "0,0,2.5").split(",").map(Number), rotation: arg("quat", "0,0,0,1").split(",").map(Number) };   // src/main.js:10-14
 
   await pathTracer.initialize();
   if (pathTracer.gpuCount() > 1) console.log("Rendering on", pathTracer.gpuCount(), "GPUs (interleaved 8x8 tiles, gather on the first)");
@@ -63,13 +68,20 @@ async function main() {
   fs.mkdirSync(path.dirname(dump), { recursive: true });
   PT.native().writeU32File(dump, bvh2U32);
   console.log("BVH2 dump complete");
+  if (flag("bvh4-wide")) {        // config C3: BVH2.bin -> BVH4_wide.bin (the reference's bin/test, tests/test.cpp:106-196), traversed as it is
+    const wide = PT.native().bvh4Wide(bvh2U32);
+    const dumpWide = arg("dump-wide", null);
+    if (dumpWide) { fs.mkdirSync(path.dirname(dumpWide), { recursive: true }); PT.native().writeU32File(dumpWide, wide); }
+    pathTracer.setBVH4(wide);
+    console.log("Traversing BVH4_wide:", wide[0], "nodes");
+  }
 
   // ---------- Render Loop ----------
   const frames = Number(arg("frames", 30));
   const batch = Number(arg("batch", 1));                      // >1: frames are traced in batches by one launch each
   if (batch > 1) pathTracer.setBatch(batch);
   let frameIndex = 0;
-  await pathTracer.render(); pathTracer.synchronize();        // warm-up (first-touch allocations)
+  if (!accumulate) { await pathTracer.render(); pathTracer.synchronize(); }        // warm-up (first-touch allocations); an accumulation counts every frame it renders
   const t0 = Date.now();
   for (let f = 0; f < frames; f++) {
     frameIndex++;
@@ -83,6 +95,9 @@ async function main() {
   const spp = mode === PT.MODE_PATH ? pathTracer.options.spp : 1;
   console.log((frames / sec).toFixed(1) + " FPS, " + (canvas.width * canvas.height * spp * frames / sec / 1e6).toFixed(1) + " Msamples/s (" + frames + " frames)");
 
+  const radiance = arg("radiance", null), trisOut = arg("triangles", null);      // what a test compares with the oracle: the last frame (f32 RGBA) and the triangles it was traced over
+  if (radiance) { const img = pathTracer.readRadiance(); fs.writeFileSync(radiance, Buffer.from(img.buffer, img.byteOffset, img.byteLength)); }
+  if (trisOut) { const t = pathTracer.trianglesData; fs.writeFileSync(trisOut, Buffer.from(t.buffer, t.byteOffset, t.byteLength)); }
   const out = arg("out", null);
   if (out) {      // what the tonemapper pass would have put on the canvas (tonemapper.wgsl)
     const rgba = pathTracer.readTonemapped(true);

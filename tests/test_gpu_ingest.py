@@ -8,6 +8,8 @@
       "Stanford Dragon (data/BVH2.bin)": the 871,414-triangle run's data/BVH2.bin, loaded by a FRESH process through setBVH2 (file -> collapse ->
       render), gives the build path's frame bit for bit (and the oracle's on a pixel grid).
 
+  C3 / C5  as worded through js/main.js with eight member contexts: BVH4_wide + 16 spp; 4K, 64 spp accumulated over 16 frames, 16 bounces.
+
 Plus the failure behaviour of the drivers: a GLB that exists and cannot be read ends the process non-zero; only an absent one falls back."""
 import os
 import re
@@ -131,6 +133,46 @@ def test_c2_bvh2_bin_reloaded_by_a_fresh_process(tmp_path, rt, orc):
     bvh4, _ = orc.collapse_bvh4(np.fromfile(dump, np.uint32), n)
     ref, _, _ = orc.render(orc.make_params(w, h, n, mode=orc_mod.MODE_PATH, spp=4, max_bounces=8, seed=1, frame=2, step=(4, 4)), tris, bvh4)
     assert same_bits(loaded[::4, ::4], ref[::4, ::4])
+
+
+EIGHT = ",".join(["0"] * 8)          # eight member contexts on the one GPU (copy transport: RCCL refuses members that share a device)
+
+
+def test_c3_through_node_wide_bvh_sixteen_spp_eight_members(tmp_path, rt, orc):
+    """C3 as worded -- "Stanford Dragon BVH4_wide, 1920x1080, 16 spp, 8 bounces, pixel-tiled across 8 GPUs" -- through the Node driver: the BVH2 of the
+    871,414-triangle scene is promoted to BVH4_wide (the reference's bin/test), written as data/BVH4_wide.bin, installed with setBVH4 and traversed by a
+    group of EIGHT member contexts (interleaved 8x8 tiles, one gather per frame; here on one GPU through the copy transport).  The file equals the oracle's
+    promotion (itself pinned against the compiled reference), the frame equals the oracle traversing that wide buffer on every 4th pixel in x and y."""
+    n, w, h = 871414, 1920, 1080
+    rc, out, err = run_node([MAIN_JS, "--devices", EIGHT, "--transport", "copy", "--mode", "2", "--spp", "16", "--bounces", "8", "--seed", "1", "--frames", "1",
+                             "--width", str(w), "--height", str(h), "--bvh4-wide", "--dump-wide", str(tmp_path / "data" / "BVH4_wide.bin"),
+                             "--dump", str(tmp_path / "data" / "BVH2.bin"), "--radiance", str(tmp_path / "img.f32"), "--triangles", str(tmp_path / "tris.f32")], str(tmp_path))
+    assert rc == 0, err
+    assert "Rendering on 8 GPUs" in out and "Traversing BVH4_wide: %d nodes" % (2 * n - 1) in out
+    tris = np.fromfile(str(tmp_path / "tris.f32"), np.float32)
+    bvh2 = np.fromfile(str(tmp_path / "data" / "BVH2.bin"), np.uint32)
+    wide = np.fromfile(str(tmp_path / "data" / "BVH4_wide.bin"), np.uint32)
+    assert wide[0] == 2 * n - 1 and np.array_equal(wide, orc.bvh4_wide(bvh2))
+    ref, _, _ = orc.render(orc.make_params(w, h, n, mode=orc_mod.MODE_PATH, spp=16, max_bounces=8, seed=1, frame=1, step=(4, 4)), tris, wide)
+    img = np.fromfile(str(tmp_path / "img.f32"), np.float32).reshape(h, w, 4)
+    assert same_bits(img[::4, ::4], ref[::4, ::4])
+
+
+def test_c5_through_node_4k_progressive_sixteen_bounces_eight_members(tmp_path, rt, orc):
+    """C5 as worded -- "3840x2160, 64 spp progressive accumulate, 16 bounces, 8 GPUs" -- through the Node driver: 16 accumulated frames of 4 spp in one
+    batch per member, eight member contexts (each keeps the running sums of its own tiles; the gather happens when the image is asked for).  The image
+    equals the oracle's 16-frame accumulation on every 8th pixel in x and y (all 64 samples each)."""
+    n, w, h, frames = 871414, 3840, 2160, 16
+    rc, out, err = run_node([MAIN_JS, "--devices", EIGHT, "--transport", "copy", "--mode", "2", "--spp", "4", "--bounces", "16", "--seed", "1", "--frames", str(frames), "--batch", str(frames),
+                             "--accumulate", "--width", str(w), "--height", str(h), "--dump", str(tmp_path / "data" / "BVH2.bin"),
+                             "--radiance", str(tmp_path / "img.f32"), "--triangles", str(tmp_path / "tris.f32")], str(tmp_path))
+    assert rc == 0, err
+    tris = np.fromfile(str(tmp_path / "tris.f32"), np.float32)
+    bvh4, _ = orc.collapse_bvh4(np.fromfile(str(tmp_path / "data" / "BVH2.bin"), np.uint32), n)
+    ref, _ = orc.render_mt(orc.make_params(w, h, n, mode=orc_mod.MODE_PATH, spp=4, max_bounces=16, seed=1, frame=1, accum_frames=frames, step=(8, 8)), tris, bvh4)
+    img = np.fromfile(str(tmp_path / "img.f32"), np.float32).reshape(h, w, 4)
+    assert same_bits(img[::8, ::8], ref[::8, ::8])
+    assert np.isfinite(img).all() and (img[..., 0] > 0.011).mean() > 0.08
 
 
 @pytest.mark.parametrize("driver", [MAIN_MJS, MAIN_JS])
