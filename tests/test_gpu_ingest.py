@@ -196,3 +196,22 @@ def test_unreadable_glb_stops_the_driver_absent_glb_falls_back(tmp_path, driver)
                                 "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}]}))
     rc, out, err = run_node([driver, "--glb", str(gltf)] + small, str(tmp_path), timeout=120)
     assert rc != 0 and "stand-in" not in out
+
+
+def test_present_step_through_the_driver_ppm_equals_the_tonemapper(tmp_path, rt, orc):
+    """NEXT-4 through the driver: `js/main.js --out frame.ppm` writes what the reference's tonemapper pass puts on the canvas (tonemapper.wgsl:24-41: Reinhard,
+    gamma 1/2.2, vertical flip, applied to the rgba8unorm output texture) -- equal to the oracle's tonemapper over the oracle's frame, byte for byte."""
+    w, h, n = 320, 180, 20000
+    ppm = tmp_path / "frame.ppm"
+    rc, out, err = run_node([MAIN_JS, "--tris", str(n), "--mode", "1", "--frames", "2", "--width", str(w), "--height", str(h), "--dump", str(tmp_path / "d" / "BVH2.bin"),
+                             "--out", str(ppm), "--radiance", str(tmp_path / "img.f32"), "--triangles", str(tmp_path / "tris.f32")], str(tmp_path), timeout=120)
+    assert rc == 0, err
+    raw = ppm.read_bytes()
+    head = ("P6\n%d %d\n255\n" % (w, h)).encode()
+    assert raw.startswith(head) and len(raw) == len(head) + w * h * 3
+    got = np.frombuffer(raw[len(head):], np.uint8).reshape(h, w, 3)
+    tris = np.fromfile(str(tmp_path / "tris.f32"), np.float32)
+    bvh4, _ = orc.collapse_bvh4(np.fromfile(str(tmp_path / "d" / "BVH2.bin"), np.uint32), n)
+    ref, _, _ = orc.render(orc.make_params(w, h, n, mode=orc_mod.MODE_SINGLE, frame=2), tris, bvh4)
+    assert same_bits(np.fromfile(str(tmp_path / "img.f32"), np.float32).reshape(h, w, 4), ref)
+    assert np.array_equal(got, orc.tonemap(ref, quantize=True)[..., :3])
