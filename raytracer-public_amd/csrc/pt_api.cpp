@@ -1242,7 +1242,8 @@ int pt_accum_info(PtContext* ctx, PtAccumInfo* out) {
 int pt_read_accum(PtContext* ctx, float* dst, uint64_t dst_floats) {
     PtAccumInfo info;
     if (int rc = pt_accum_info(ctx, &info)) return rc;
-    if (info.floats == 0) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_accum: no running accumulation (render with accumulate = 1 first)");
+    if (info.samples == 0) return fail(ctx, PT_ERR_NO_SCENE, "pt_read_accum: no running accumulation (render with accumulate = 1 first)");
+    if (info.floats == 0) return PT_OK;             // a share that owns no tile (more shares than tiles): a running accumulation of nothing
     if (!dst || dst_floats < info.floats) return fail(ctx, PT_ERR_INVALID_ARG, "pt_read_accum: destination too small (pt_accum_info gives the size)");
     const DevBuf<float4>& acc = info.compact ? ctx->d_compact_accum : ctx->d_accum;
     PT_HIP(ctx, hipMemcpyAsync(dst, acc.ptr, info.floats * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

@@ -364,6 +364,8 @@ def test_accumulation_checkpoint_at_ragged_resolutions(rt, gpu_ctx, w, h):
         assert len(rt.tile_ids(w, h, 4000, 4095)) == 0
         fresh.set_accum(empty, np.zeros(0, np.float32))
         assert fresh.accum_info().samples == 4 and fresh.accum_info().floats == 0
+        einfo, edump = fresh.read_accum()                                       # ... and reads back as what it is: nothing
+        assert einfo.samples == 4 and edump.size == 0
     finally:
         fresh.close()
 
