@@ -697,7 +697,9 @@ def run_bench(args, rank, world, device, backend, torch, dist, np, rt):
         # labelled, and never the headline.
         GUIDE, PROBE = "guide", "self-measured"
         resources = {
-            "valu_issue": ("valu", lambda c: c["SQ_INSTS_VALU"], VALU_PEAK_GINST, "Ginst/s", GUIDE, "SIMD-32: 2 cycles per wave64 instruction, 1,024 SIMDs, 2.4 GHz"),
+            "valu_issue": ("valu", lambda c: c["SQ_INSTS_VALU"], VALU_PEAK_GINST, "Ginst/s", GUIDE,
+                           "SIMD-32: 2 cycles per wave64 instruction, 1,024 SIMDs, 2.4 GHz; plain f32 FMA / mul / min-max chains sustain 1,068-1,081 G/s = 0.87-0.88 of it with this kernel's six "
+                           "wavefronts per SIMD, 1,097 with eight (tools/probes/valu_rate.hip, profiles/r06_valu_rate_probe.txt)"),
             "l2_bandwidth": ("l2", lambda c: (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * L2_LINE, L2_PEAK_GBS, "GB/s", GUIDE, "34.5 TB/s aggregate, 128-byte lines"),
             "hbm_fabric": ("hbm", lambda c: (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, HBM_PEAK_GBS, "GB/s", GUIDE, "8 TB/s (FETCH_SIZE includes Infinity-Cache hits)"),
             "salu_issue": ("salu", lambda c: c["SQ_INSTS_SALU"], SALU_PEAK_GINST, "Ginst/s", PROBE,
